@@ -1,0 +1,152 @@
+/*
+ * g2s.h — C ABI of libg2s.so, the MI355X (gfx950) native kernels behind the GAN2Shape
+ * inner loop.  This header is the drop-in boundary: every entry point replaces one native
+ * (CUDA) interface the reference binds by name.  Reference citations are relative to
+ * /root/reference (alessioGalatolo/GAN-2D-to-3D).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless stated;
+ *   - the caller owns and allocates every buffer (the library never allocates device memory,
+ *     never synchronises, never throws);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - returns G2S_OK (0) or a negative error code; g2s_last_error() gives a thread-local message;
+ *   - re-entrant; no global mutable state besides the error string.
+ */
+#ifndef G2S_H
+#define G2S_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G2S_ABI_VERSION 1
+
+#define G2S_OK 0
+#define G2S_ERR_INVALID (-1)   /* bad argument (shape / pointer / dtype / unsupported combination) */
+#define G2S_ERR_LAUNCH (-2)    /* hipLaunchKernel / hipMemsetAsync reported an error              */
+#define G2S_ERR_WORKSPACE (-3) /* workspace too small                                              */
+
+#define G2S_F32 0
+#define G2S_F16 1
+
+typedef void *g2s_stream_t; /* hipStream_t */
+
+int g2s_abi_version(void);
+const char *g2s_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Differentiable depth rasterizer.
+ * Replaces neural_renderer.Renderer.render_depth(vertices, faces) as called from
+ * GAN2Shape/renderer/renderer.py:47-54 (constructor: camera_mode='projection', K, R=I, t=0,
+ * fill_back=True, anti_aliasing=True) and :116-125 (warp_canon_depth).  neural_renderer is an
+ * external, un-vendored CUDA package (README.md:32-37); semantics per SURVEY.md Appendix A.
+ *
+ * verts      [B, n_verts, 3] f32, camera-space xyz (after the view transform)
+ * faces      [n_faces, 3] i32 vertex ids shared by the whole batch, or NULL = the implicit
+ *            regular-grid topology of renderer/utils.py:76-80 get_face_idx(b, S, S) with
+ *            n_verts == S*S and n_faces == 2*(S-1)*(S-1)
+ * K          HOST pointer, 9 floats row-major, pinhole intrinsics (third row must be 0 0 1)
+ * orig_size  neural_renderer `orig_size` (== S here)
+ * S          output image size; the raster runs at ssaa*S (ssaa 1 or 2; 2 == anti_aliasing)
+ * fill_back  1: each face is also rendered with reversed vertex order (face id + n_faces)
+ * depth_out  [B, S, S] f32  after vertical flip and ssaa x ssaa average pooling (un-clamped;
+ *            background = far)
+ * face_idx_out [B, ssaa*S, ssaa*S] i32 winning face id (-1 background) in UNFLIPPED raster rows,
+ *            or NULL when no backward is needed
+ * bary_out   [B, ssaa*S, ssaa*S, 3] f32 clamped+renormalised barycentric weights of the winner,
+ *            or NULL (must be NULL iff face_idx_out is NULL)
+ * workspace  >= g2s_raster_workspace_bytes(B, n_verts, n_faces, S) bytes of device scratch
+ * ---------------------------------------------------------------------------------------- */
+size_t g2s_raster_workspace_bytes(int B, int n_verts, int n_faces, int S);
+
+int g2s_raster_depth_fwd(const float *verts, const int32_t *faces, int B, int n_verts, int n_faces,
+                         int S, const float *K, float orig_size, int ssaa, int fill_back,
+                         float near, float far, float *depth_out, int32_t *face_idx_out,
+                         float *bary_out, void *workspace, size_t workspace_bytes,
+                         g2s_stream_t stream);
+
+/* Backward of the above w.r.t. verts (neural_renderer backward_depth_map + vertices_to_faces +
+ * projection backward).
+ * grad_depth [B, S, S] f32 (gradient of depth_out); grad_verts [B, n_verts, 3] f32 is zero-filled
+ * by the callee, then accumulated with float atomics. */
+int g2s_raster_depth_bwd(const float *verts, const int32_t *faces, const float *grad_depth,
+                         const int32_t *face_idx, const float *bary, int B, int n_verts,
+                         int n_faces, int S, const float *K, float orig_size, int ssaa,
+                         float *grad_verts, g2s_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fused bias + activation.
+ * Replaces fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)
+ * (GAN2Shape/stylegan2/stylegan2-pytorch/op/fused_bias_act.cpp:11-20,
+ *  op/fused_bias_act_kernel.cu:19-99).
+ *   y[i] = f(x[i] + bias[(i / step_b) % size_b]) * scale
+ *   act*10+grad: 10,11 -> identity ; 12 -> 0 ; 30 -> lrelu(alpha) ; 31 -> ref>0 ? x : x*alpha ;
+ *   32 -> 0 ; anything else -> identity.
+ * bias / ref may be NULL (== the reference's 0-element tensors). dtype G2S_F32 or G2S_F16.
+ * ---------------------------------------------------------------------------------------- */
+int g2s_fused_bias_act(const void *x, const void *bias, const void *ref, void *y, int64_t n,
+                       int64_t step_b, int64_t size_b, int act, int grad, float alpha,
+                       float scale, int dtype, g2s_stream_t stream);
+
+/* StyledConv tail in one pass (stylegan2-pytorch/model.py:349-355: NoiseInjection then
+ * FusedLeakyReLU): y = lrelu_alpha(x + noise_w * noise[hw] + bias[c]) * scale.
+ * x,y [B, C, HW] f32; noise [HW] f32 (one map broadcast over B and C) or NULL;
+ * noise_w is a DEVICE pointer to 1 float. */
+int g2s_noise_bias_act(const float *x, const float *noise, const float *noise_w,
+                       const float *bias, float *y, int B, int C, int HW, float alpha,
+                       float scale, g2s_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * upfirdn2d.
+ * Replaces upfirdn2d_op.upfirdn2d(input[M,H,W,1], kernel[kh,kw], up_x, up_y, down_x, down_y,
+ * pad_x0, pad_x1, pad_y0, pad_y1) (op/upfirdn2d.cpp:12-22, op/upfirdn2d_kernel.cu:209-369).
+ * x [major, in_h, in_w] (minor == 1), k [kh, kw] f32 on device, y [major, out_h, out_w] with
+ * out = (in*up + pad0 + pad1 - k + down) / down.  Negative pads crop.
+ * ---------------------------------------------------------------------------------------- */
+int g2s_upfirdn2d(const void *x, const float *k, void *y, int major, int in_h, int in_w, int kh,
+                  int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                  int pad_y0, int pad_y1, int dtype, g2s_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Modulated convolution (StyleGAN2 generator), fp32 MFMA implicit GEMM.
+ * Replaces the grouped F.conv2d / F.conv_transpose2d inside ModulatedConv2d.forward
+ * (stylegan2-pytorch/model.py:250-291) using the input-scaling formulation
+ *     y[b,o] = demod[b,o] * sum_{i,ky,kx} Wt[o,i,ky,kx] * (style[b,i] * x[b,i, .+ky, .+kx])
+ * which equals the reference's per-sample-weight formulation up to fp32 rounding.
+ *
+ * mode G2S_CONV_PLAIN : stride 1, zero padding k/2                 (model.py:286-289)
+ *      G2S_CONV_UP2   : transposed conv stride 2, padding 0, out = 2*H+1 (model.py:264-274;
+ *                       the following Blur is g2s_upfirdn2d)
+ *      G2S_CONV_DOWN2 : stride-2 conv, padding 0, out = (H-k)/2+1  (adjoint of UP2; model.py:277-283)
+ * x      [B, Cin, H, W] f32
+ * w      [Cout, Cin, k, k] f32, already multiplied by the 1/sqrt(fan_in) scale, k in {1,3}
+ * style  [B, Cin] f32 or NULL (no modulation)       — multiplies the input channels
+ * demod  [B, Cout] f32 or NULL (no demodulation)    — multiplies the output channels
+ * y      [B, Cout, Ho, Wo] f32
+ * flip_transpose 1: use w as its own adjoint (channels swapped: w is still [Cout_of_fwd, Cin_of_fwd,
+ *        k, k], taps flipped) so that bwd-data needs no weight repack:
+ *        then x has Cout_of_fwd channels (scaled by `style` == demod of fwd) and y has Cin_of_fwd
+ *        channels (scaled by `demod` == style of fwd).
+ * ---------------------------------------------------------------------------------------- */
+#define G2S_CONV_PLAIN 0
+#define G2S_CONV_UP2 1
+#define G2S_CONV_DOWN2 2
+
+int g2s_modconv(const float *x, const float *w, const float *style, const float *demod, float *y,
+                int B, int Cin, int Cout, int H, int W, int k, int mode, int flip_transpose,
+                g2s_stream_t stream);
+
+/* demod[b,o] = rsqrt( sum_i (sum_{ky,kx} w[o,i,ky,kx]^2) * style[b,i]^2 + eps )
+ * (model.py:256-258 with weight = scale*W*style).  wsq [Cout, Cin] = sum over taps of w^2 is
+ * produced by g2s_modconv_wsq. */
+int g2s_modconv_wsq(const float *w, float *wsq, int Cout, int Cin, int k, g2s_stream_t stream);
+int g2s_modconv_demod(const float *wsq, const float *style, float *demod, int B, int Cin, int Cout,
+                      float eps, g2s_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G2S_H */

@@ -1,0 +1,104 @@
+"""Pin the C oracle (oracle/g2s_oracle.c) against golden vectors generated from the reference's
+own Python (tests/golden/make_golden.py): op/upfirdn2d.py:157-198, op/fused_act.py:86-92,
+stylegan2-pytorch/model.py:250-291."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import capi
+
+UP_CASES = ["blur_up", "rgb_up", "d_blur3", "d_blur1", "down2", "crop"]
+
+
+@pytest.mark.parametrize("name", UP_CASES)
+def test_upfirdn2d_forward(golden, name):
+    g = golden("ops")
+    up, down, p0, p1 = (int(v) for v in g[f"upfirdn2d.{name}.args"])
+    y = capi.upfirdn2d(g[f"upfirdn2d.{name}.x"], g[f"upfirdn2d.{name}.k"], (up, up), (down, down),
+                       (p0, p1, p0, p1))
+    assert y.shape == g[f"upfirdn2d.{name}.y"].shape
+    np.testing.assert_allclose(y, g[f"upfirdn2d.{name}.y"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", UP_CASES)
+def test_upfirdn2d_backward_is_adjoint_op(golden, name):
+    """op/upfirdn2d.py:100-115: the gradient is the same op with up/down swapped, the flipped
+    kernel and g_pad."""
+    g = golden("ops")
+    up, down, p0, p1 = (int(v) for v in g[f"upfirdn2d.{name}.args"])
+    x, k, gy = g[f"upfirdn2d.{name}.x"], g[f"upfirdn2d.{name}.k"], g[f"upfirdn2d.{name}.gy"]
+    kh, kw = k.shape
+    in_h, in_w = x.shape[2:]
+    out_h, out_w = gy.shape[2:]
+    gp_x0 = kw - p0 - 1
+    gp_y0 = kh - p0 - 1
+    gp_x1 = in_w * up - out_w * down + p0 - up + 1
+    gp_y1 = in_h * up - out_h * down + p0 - up + 1
+    gx = capi.upfirdn2d(gy, k[::-1, ::-1].copy(), (down, down), (up, up), (gp_x0, gp_x1, gp_y0, gp_y1))
+    np.testing.assert_allclose(gx, g[f"upfirdn2d.{name}.gx"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["4d", "2d"])
+def test_fused_bias_act(golden, name):
+    g = golden("ops")
+    x, b, gy = g[f"fused.{name}.x"], g[f"fused.{name}.b"], g[f"fused.{name}.gy"]
+    y = capi.fused_bias_act(x, b, None, 3, 0, 0.2, math.sqrt(2))
+    np.testing.assert_allclose(y, g[f"fused.{name}.y"], rtol=1e-6, atol=1e-7)
+    # backward form (op/fused_act.py:20-38): act=3, grad=1, ref = forward output, no bias
+    gx = capi.fused_bias_act(gy, None, y, 3, 1, 0.2, math.sqrt(2))
+    np.testing.assert_allclose(gx, g[f"fused.{name}.gx"], rtol=1e-6, atol=1e-7)
+    dims = (0,) + tuple(range(2, gx.ndim))
+    np.testing.assert_allclose(gx.sum(dims), g[f"fused.{name}.gb"], rtol=1e-5, atol=1e-6)
+
+
+def test_fused_bias_act_other_modes():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 3, 4)).astype(np.float32)
+    b = rng.standard_normal(3).astype(np.float32)
+    xb = x + b[None, :, None]
+    np.testing.assert_array_equal(capi.fused_bias_act(x, b, None, 1, 0, 0.2, 2.0), xb * 2.0)
+    np.testing.assert_array_equal(capi.fused_bias_act(x, b, None, 3, 2, 0.2, 2.0), np.zeros_like(x))
+    np.testing.assert_array_equal(capi.fused_bias_act(x, None, None, 1, 2, 0.2, 2.0), np.zeros_like(x))
+
+
+def _style_mod(g, name):
+    """EqualLinear(style_dim, cin, bias_init=1) — model.py:157-167, lr_mul=1."""
+    w, b, s = g[f"{name}.mod_weight"], g[f"{name}.mod_bias"], g[f"{name}.s"]
+    return (s @ (w * (1 / math.sqrt(w.shape[1]))).T + b).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,mode,demod", [("plain", 0, True), ("rgb", 0, False)])
+def test_modconv_plain(golden, name, mode, demod):
+    g = golden("modconv")
+    w = g[f"{name}.weight"][0]
+    scale = 1 / math.sqrt(w.shape[1] * w.shape[2] ** 2)
+    y = capi.modconv(g[f"{name}.x"], w, _style_mod(g, name), scale, demod, mode)
+    np.testing.assert_allclose(y, g[f"{name}.y"], rtol=1e-4, atol=1e-5)
+
+
+def test_modconv_upsample_then_blur(golden):
+    """model.py:264-275: conv_transpose2d stride 2, then Blur(pad=(1,1), kernel*4)."""
+    g = golden("modconv")
+    w = g["up.weight"][0]
+    scale = 1 / math.sqrt(w.shape[1] * 9)
+    style = _style_mod(g, "up")
+    np.testing.assert_allclose(style, g["up.style_mod"], rtol=1e-5, atol=1e-6)
+    y = capi.modconv(g["up.x"], w, style, scale, True, 1)
+    assert y.shape[2] == 2 * g["up.x"].shape[2] + 1
+    k = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32)
+    k = k / k.sum() * 4
+    y = capi.upfirdn2d(y, k, pad=(1, 1, 1, 1))
+    np.testing.assert_allclose(y, g["up.y"], rtol=1e-4, atol=1e-5)
+
+
+def test_modconv_downsample_after_blur(golden):
+    """model.py:277-283: Blur(pad=(2,2)) then conv2d stride 2."""
+    g = golden("modconv")
+    w = g["down.weight"][0]
+    scale = 1 / math.sqrt(w.shape[1] * 9)
+    k = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32)
+    k = k / k.sum()
+    xb = capi.upfirdn2d(g["down.x"], k, pad=(2, 2, 2, 2))
+    y = capi.modconv(xb, w, _style_mod(g, "down"), scale, True, 2)
+    np.testing.assert_allclose(y, g["down.y"], rtol=1e-4, atol=1e-5)
