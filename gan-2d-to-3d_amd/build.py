@@ -1,0 +1,65 @@
+"""Build libg2s.so (hand-written HIP kernels for gfx950 + the C ABI of include/g2s.h).
+
+    python gan-2d-to-3d_amd/build.py [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  Objects and the library stay in-tree
+(gan-2d-to-3d_amd/lib/, git-ignored) so that they travel to the GPU box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libg2s.so")
+ARCH = "gfx950"
+
+SOURCES = {
+    # file: extra flags
+    "api.hip": [],
+    "raster.hip": ["-ffp-contract=off"],  # bit-parity with the oracle's unfused arithmetic
+    "fused_bias_act.hip": [],
+    "upfirdn2d.hip": [],
+    "modconv.hip": [],
+    "geometry.hip": ["-ffp-contract=off"],
+}
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(src, dst, deps):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(d) > t for d in [src] + deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "g2s.h"))
+    objs = []
+    relink = force
+    for name, extra in SOURCES.items():
+        src = os.path.join(CSRC, name)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(LIBDIR, name.replace(".hip", ".o"))
+        if force or _newer(src, obj, headers):
+            cmd = [hipcc] + COMMON + extra + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            relink = True
+        objs.append(obj)
+    if relink or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

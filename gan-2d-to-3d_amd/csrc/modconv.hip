@@ -1,0 +1,303 @@
+// modconv.hip — StyleGAN2 modulated convolution as an fp32-MFMA implicit GEMM for gfx950.
+//
+// Replaces the grouped F.conv2d / F.conv_transpose2d of ModulatedConv2d.forward
+// (GAN2Shape/stylegan2/stylegan2-pytorch/model.py:250-291) and their data-gradients.
+// The reference materialises one weight set per sample (B*Cout*Cin*9 floats) and runs a grouped
+// convolution with B groups.  Here the weights stay shared and batch-independent:
+//     y[b,o] = demod[b,o] * sum_{i,t} W[o,i,t] * (style[b,i] * x[b,i,.])
+// so the whole batch is ONE GEMM  C[M = out channels][N = B*OH*OW] = A[M][K] * Bm[K][N]  with
+//   A  = the weight tensor itself, gathered in place (no packing; the transposed use for the
+//        data-gradient only changes two strides),
+//   Bm = im2col of x, never materialised: gathered from global memory straight into LDS with the
+//        per-(b,i) style scale applied on the way,
+//   epilogue = per-(b,o) demodulation scale.
+// v_mfma_f32_32x32x2_f32 (exact fp32, 256 FLOP/clk/CU) — results differ from an fp32 FMA chain
+// only by summation order.  LDS holds k-major operand tiles so that the MFMA operand fetch is a
+// conflict-free ds_read_b32 (lanes 0-31 consecutive, lanes 32-63 the next k row).  Global loads
+// for tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after
+// them (one barrier per K tile).
+//
+// The transposed convolution (UP2) is run as its four output-parity classes (4/2/2/1 taps): no
+// multiplications by inserted zeros; classes are blockIdx.z of one launch.
+// Small layers (4x4 .. 16x16) use 64x64 tiles and split-K with float atomics to fill 256 CUs.
+#include "g2s_common.h"
+
+namespace g2s {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int NTHREADS = 256;
+
+struct ConvClass {  // one output-parity class (a single class for gather geometries)
+    int OH, OW;     // class output extent
+    int T;          // taps in this class
+    int oy0, ox0;   // offset of the class in the full output
+    int tab[9];     // per tap: (dy + 8) | (dx + 8) << 8 | wtap << 16
+};
+
+struct ConvDesc {
+    const float *x, *w, *in_scale, *out_scale;
+    float *y;
+    int B, Cr, M;        // batch, reduction channels, output channels
+    int H, W;            // input spatial size
+    int OHf, OWf;        // full output spatial size
+    int w_ms, w_ks;      // strides (in floats) of the m index and the reduction-channel index in w
+    int is;              // input stride of the gather (1 or 2)
+    int os;              // output stride of a class (1, or 2 for the polyphase classes)
+    int ncls;
+    int splitk;
+    ConvClass cls[4];
+};
+
+template <int BM, int BN, int T>
+__device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass &c,
+                                             float (&As)[2][BK][BM + 1], float (&Bs)[2][BK][BN],
+                                             const int (&stab)[9]) {
+    constexpr int WMT = BM / 64, WNT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
+    constexpr int EA = BM * BK / NTHREADS, EB = BN * BK / NTHREADS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Ncls = d.B * c.OH * c.OW;
+    const int tiles_m = (d.M + BM - 1) / BM;
+    const int m0 = (blockIdx.x % tiles_m) * BM;
+    const int n0 = (blockIdx.x / tiles_m) * BN;
+    const int Kc = d.Cr * T;
+    const int ktiles = (Kc + BK - 1) / BK;
+    const int per = (ktiles + d.splitk - 1) / d.splitk;
+    const int kt_begin = blockIdx.y * per;
+    const int kt_end = min(ktiles, kt_begin + per);
+
+    // ---- this thread's im2col column (fixed over the K loop)
+    const int nB = tid % BN;
+    const int kB0 = tid / BN;  // + e * (NTHREADS / BN)
+    const int ng = n0 + nB;
+    const bool n_ok = ng < Ncls;
+    int bb = 0, iy0 = 0, ix0 = 0;
+    if (n_ok) {
+        bb = ng / (c.OH * c.OW);
+        const int r = ng % (c.OH * c.OW);
+        iy0 = (r / c.OW) * d.is;
+        ix0 = (r % c.OW) * d.is;
+    }
+    const float *xb = d.x + (size_t)bb * d.Cr * d.H * d.W;
+    const float *sb = d.in_scale ? d.in_scale + (size_t)bb * d.Cr : nullptr;
+    // ---- this thread's weight elements: lanes run along k (contiguous taps)
+    const int kA = tid % BK;
+    const int mA0 = tid / BK;  // + e * (NTHREADS / BK)
+
+    float ra[EA], rb[EB];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int e = 0; e < EA; e++) {
+            const int m = m0 + mA0 + e * (NTHREADS / BK);
+            const int kg = kt * BK + kA;
+            float v = 0.0f;
+            if (m < d.M && kg < Kc) {
+                const int ch = kg / T, t = kg - ch * T;
+                v = d.w[(size_t)m * d.w_ms + (size_t)ch * d.w_ks + (stab[t] >> 16)];
+            }
+            ra[e] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < EB; e++) {
+            const int kg = kt * BK + kB0 + e * (NTHREADS / BN);
+            float v = 0.0f;
+            if (n_ok && kg < Kc) {
+                const int ch = kg / T, t = kg - ch * T;
+                const int tb = stab[t];
+                const int iy = iy0 + (tb & 0xff) - 8, ix = ix0 + ((tb >> 8) & 0xff) - 8;
+                if (iy >= 0 && iy < d.H && ix >= 0 && ix < d.W) {
+                    v = xb[((size_t)ch * d.H + iy) * d.W + ix];
+                    if (sb) v *= sb[ch];
+                }
+            }
+            rb[e] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < EA; e++) As[buf][kA][mA0 + e * (NTHREADS / BK)] = ra[e];
+#pragma unroll
+        for (int e = 0; e < EB; e++) Bs[buf][kB0 + e * (NTHREADS / BN)][nB] = rb[e];
+    };
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; i++)
+#pragma unroll
+        for (int j = 0; j < WNT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    load_tile(kt_begin);
+    store_tile(0);
+    __syncthreads();
+    const int l31 = lane & 31, lk = lane >> 5;
+    for (int kt = kt_begin; kt < kt_end; kt++) {
+        const int buf = (kt - kt_begin) & 1;
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tile(kt + 1);  // global loads in flight during the MFMAs below
+#pragma unroll
+        for (int k2 = 0; k2 < BK; k2 += 2) {
+            float a[WMT], b[WNT];
+#pragma unroll
+            for (int i = 0; i < WMT; i++) a[i] = As[buf][k2 + lk][wm * (BM / 2) + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < WNT; j++) b[j] = Bs[buf][k2 + lk][wn * (BN / 2) + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < WMT; i++)
+#pragma unroll
+                for (int j = 0; j < WNT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C[m][n], m = (r&3) + 8*(r>>2) + 4*(lane>>5), n = lane&31 within a 32x32 tile
+#pragma unroll
+    for (int j = 0; j < WNT; j++) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+        if (n >= Ncls) continue;
+        const int b = n / (c.OH * c.OW);
+        const int r_ = n % (c.OH * c.OW);
+        const int oy = (r_ / c.OW) * d.os + c.oy0, ox = (r_ % c.OW) * d.os + c.ox0;
+        float *yb = d.y + ((size_t)b * d.M * d.OHf + oy) * d.OWf + ox;
+        const float *ob = d.out_scale ? d.out_scale + (size_t)b * d.M : nullptr;
+#pragma unroll
+        for (int i = 0; i < WMT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= d.M) continue;
+                float v = acc[i][j][r];
+                if (ob) v *= ob[m];
+                float *dst = yb + (size_t)m * d.OHf * d.OWf;
+                if (d.splitk > 1) unsafeAtomicAdd(dst, v);
+                else *dst = v;
+            }
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
+    __shared__ float As[2][BK][BM + 1];
+    __shared__ float Bs[2][BK][BN];
+    __shared__ int stab[9];
+    const ConvClass &c = d.cls[blockIdx.z];
+    // uniform early exits: smaller parity classes need fewer tiles; empty split-K slices
+    const int tiles_m = (d.M + BM - 1) / BM;
+    if ((int)(blockIdx.x / tiles_m) * BN >= d.B * c.OH * c.OW) return;
+    const int ktiles = (d.Cr * c.T + BK - 1) / BK;
+    const int per = (ktiles + d.splitk - 1) / d.splitk;
+    if ((int)blockIdx.y * per >= ktiles) return;
+    if (threadIdx.x < 9) stab[threadIdx.x] = c.tab[threadIdx.x];
+    __syncthreads();
+    switch (c.T) {  // compile-time tap count: k / T becomes a multiply-shift
+    case 9: modconv_body<BM, BN, 9>(d, c, As, Bs, stab); break;
+    case 4: modconv_body<BM, BN, 4>(d, c, As, Bs, stab); break;
+    case 2: modconv_body<BM, BN, 2>(d, c, As, Bs, stab); break;
+    default: modconv_body<BM, BN, 1>(d, c, As, Bs, stab); break;
+    }
+}
+
+static int pack(int dy, int dx, int wt) { return (dy + 8) | ((dx + 8) << 8) | (wt << 16); }
+
+}  // namespace g2s
+
+using namespace g2s;
+
+extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale,
+                           const float *out_scale, float *y, int B, int Cin, int Cout, int H, int W,
+                           int k, int mode, int transpose, g2s_stream_t stream) {
+    G2S_REQUIRE(x && w && y, "x, w, y must not be NULL");
+    G2S_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "sizes must be positive");
+    G2S_REQUIRE(k == 1 || k == 3, "kernel size must be 1 or 3 (got %d)", k);
+    G2S_REQUIRE(mode == G2S_CONV_PLAIN || ((mode == G2S_CONV_UP2 || mode == G2S_CONV_DOWN2) && k == 3),
+                "unsupported mode %d with k=%d", mode, k);
+    ConvDesc d{};
+    d.x = x;
+    d.w = w;
+    d.in_scale = in_scale;
+    d.out_scale = out_scale;
+    d.y = y;
+    d.B = B;
+    d.H = H;
+    d.W = W;
+    const int KK = k * k, pad = k / 2;
+    d.Cr = transpose ? Cout : Cin;
+    d.M = transpose ? Cin : Cout;
+    d.w_ms = transpose ? KK : Cin * KK;
+    d.w_ks = transpose ? Cin * KK : KK;
+    // geometry: gather (stride 1 or 2) or polyphase scatter
+    const bool scatter = (mode == G2S_CONV_UP2 && !transpose) || (mode == G2S_CONV_DOWN2 && transpose);
+    if (!scatter) {
+        d.ncls = 1;
+        d.os = 1;
+        ConvClass &c = d.cls[0];
+        c.T = KK;
+        c.oy0 = c.ox0 = 0;
+        if (mode == G2S_CONV_PLAIN) {
+            d.is = 1;
+            d.OHf = H;
+            d.OWf = W;
+            for (int ky = 0; ky < k; ky++)
+                for (int kx = 0; kx < k; kx++)
+                    c.tab[ky * k + kx] = transpose ? pack(pad - ky, pad - kx, ky * k + kx)
+                                                   : pack(ky - pad, kx - pad, ky * k + kx);
+        } else {  // strided gather: DOWN2 forward, or the adjoint of UP2
+            G2S_REQUIRE(H >= k && W >= k, "input smaller than the kernel");
+            d.is = 2;
+            d.OHf = (H - k) / 2 + 1;
+            d.OWf = (W - k) / 2 + 1;
+            for (int ky = 0; ky < k; ky++)
+                for (int kx = 0; kx < k; kx++) c.tab[ky * k + kx] = pack(ky, kx, ky * k + kx);
+        }
+        c.OH = d.OHf;
+        c.OW = d.OWf;
+    } else {
+        // y[2*iy + ky] += x[iy] w[ky]: output parity p uses taps ky == p (mod 2), iy = oy' + (p - ky)/2
+        d.is = 1;
+        d.os = 2;
+        d.OHf = (H - 1) * 2 + k;
+        d.OWf = (W - 1) * 2 + k;
+        d.ncls = 4;
+        for (int py = 0; py < 2; py++)
+            for (int px = 0; px < 2; px++) {
+                ConvClass &c = d.cls[py * 2 + px];
+                c.oy0 = py;
+                c.ox0 = px;
+                c.OH = (d.OHf - py + 1) / 2;
+                c.OW = (d.OWf - px + 1) / 2;
+                c.T = 0;
+                for (int ky = py; ky < k; ky += 2)
+                    for (int kx = px; kx < k; kx += 2)
+                        c.tab[c.T++] = pack((py - ky) / 2, (px - kx) / 2, ky * k + kx);
+            }
+    }
+    // tile configuration + split-K: aim for >= 2 workgroups per CU
+    long nmax = 0;
+    int tmin = 9;
+    for (int i = 0; i < d.ncls; i++) {
+        nmax = std::max(nmax, (long)B * d.cls[i].OH * d.cls[i].OW);
+        tmin = std::min(tmin, d.cls[i].T);
+    }
+    G2S_REQUIRE(nmax < (1l << 30), "problem too large");
+    hipStream_t st = as_stream(stream);
+    const bool big = d.M >= 128 && nmax >= 128 * 64;
+    const int BMv = big ? 128 : 64, BNv = big ? 128 : 64;
+    const int tiles = cdiv(d.M, BMv) * cdiv(nmax, BNv);
+    const int ktiles_min = cdiv((long)d.Cr * tmin, BK);
+    int splitk = 1;
+    while (tiles * d.ncls * splitk < 256 && splitk * 2 <= ktiles_min / 4 && splitk < 64) splitk *= 2;
+    d.splitk = splitk;
+    if (splitk > 1) {
+        if (hipMemsetAsync(y, 0, (size_t)B * d.M * d.OHf * d.OWf * sizeof(float), st) != hipSuccess)
+            return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
+    }
+    dim3 grid(tiles, splitk, d.ncls);
+    if (big) modconv_kernel<128, 128><<<grid, NTHREADS, 0, st>>>(d);
+    else modconv_kernel<64, 64><<<grid, NTHREADS, 0, st>>>(d);
+    return check_launch("g2s_modconv");
+}

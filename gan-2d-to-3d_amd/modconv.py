@@ -1,0 +1,113 @@
+"""Autograd wrapper of g2s_modconv (libg2s.so) — the grouped convolution of
+ModulatedConv2d.forward (GAN2Shape/stylegan2/stylegan2-pytorch/model.py:250-291) in the
+input-scaling formulation
+
+    y[b,o] = demod[b,o] * sum_{i,t} w[o,i,t] * (s[b,i] * x[b,i,.])
+
+Gradients (all on the GPU, no CPU path):
+    gx  = s      * conv^T(w, demod * gy)            one more MFMA GEMM (transpose=1, same weights)
+    gs  = sum_hw x * conv^T(w, demod * gy)          reduction of the same GEMM output
+    gd  = sum_hw gy * y / demod
+    gw  (only if the weight requires grad — never on GAN2Shape's path, where G is frozen:
+         GAN2Shape/model.py:26-37 keeps G in eval mode and no optimiser owns it) via torch's conv
+         weight-gradient.
+"""
+import torch
+from torch.autograd import Function
+
+from . import lib as _lib
+
+PLAIN, UP2, DOWN2 = _lib.CONV_PLAIN, _lib.CONV_UP2, _lib.CONV_DOWN2
+
+
+def out_size(h, k, mode):
+    if mode == PLAIN:
+        return h
+    if mode == UP2:
+        return (h - 1) * 2 + k
+    return (h - k) // 2 + 1
+
+
+def modconv_raw(x, w, in_scale, out_scale, mode, transpose):
+    """Direct call of g2s_modconv.  w is always [Cout, Cin, k, k]."""
+    _lib.require_cuda(x, w, in_scale, out_scale)
+    if x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise RuntimeError("modconv: float32 only")
+    x = x.contiguous()
+    w = w.contiguous()
+    B, C, H, W = x.shape
+    Cout, Cin, k, _ = w.shape
+    if C != (Cout if transpose else Cin):
+        raise RuntimeError(f"modconv: x has {C} channels, expected {Cout if transpose else Cin}")
+    if transpose:
+        # adjoint geometry: UP2^T gathers with stride 2, DOWN2^T scatters
+        oh = {PLAIN: H, UP2: (H - k) // 2 + 1, DOWN2: (H - 1) * 2 + k}[mode]
+        ow = {PLAIN: W, UP2: (W - k) // 2 + 1, DOWN2: (W - 1) * 2 + k}[mode]
+        cy = Cin
+    else:
+        oh, ow = out_size(H, k, mode), out_size(W, k, mode)
+        cy = Cout
+    for name, t, c in (("in_scale", in_scale, C), ("out_scale", out_scale, cy)):
+        if t is not None and (t.shape != (B, c) or t.dtype != torch.float32):
+            raise RuntimeError(f"modconv: {name} must be float32 [{B}, {c}]")
+    y = torch.empty((B, cy, oh, ow), dtype=torch.float32, device=x.device)
+    si = None if in_scale is None else in_scale.contiguous()
+    so = None if out_scale is None else out_scale.contiguous()
+    L = _lib.load()
+    _lib.check(L.g2s_modconv(_lib.ptr(x), _lib.ptr(w), _lib.ptr(si), _lib.ptr(so), _lib.ptr(y), B,
+                             Cin, Cout, H, W, k, mode, int(transpose), _lib.stream()))
+    return y
+
+
+class ModConvFunction(Function):
+    @staticmethod
+    def forward(ctx, x, w, s, demod, mode):
+        y = modconv_raw(x, w, s, demod, mode, 0)
+        ctx.mode = mode
+        ctx.has_s, ctx.has_d = s is not None, demod is not None
+        need_y = demod is not None and ctx.needs_input_grad[3]
+        ctx.save_for_backward(x, w, s, demod, y if need_y else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, s, demod, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gs = gd = None
+        if ctx.needs_input_grad[0] or (ctx.has_s and ctx.needs_input_grad[2]):
+            gxs = modconv_raw(gy, w, demod, None, ctx.mode, 1)  # gradient w.r.t. (s * x)
+            if ctx.has_s:
+                if ctx.needs_input_grad[2]:
+                    gs = (x * gxs).sum((2, 3))
+                if ctx.needs_input_grad[0]:
+                    gx = gxs * s[:, :, None, None]
+            else:
+                gx = gxs
+        if ctx.has_d and ctx.needs_input_grad[3]:
+            gd = (gy * y).sum((2, 3)) / demod
+        if ctx.needs_input_grad[1]:
+            gw = _weight_grad(x, w, s, demod, gy, ctx.mode)
+        return gx, gw, gs, gd, None
+
+
+def _weight_grad(x, w, s, demod, gy, mode):
+    """Off the hot path (G is frozen in GAN2Shape): weight gradient through torch's conv."""
+    import torch.nn.functional as F
+    xs = x if s is None else x * s[:, :, None, None]
+    g = gy if demod is None else gy * demod[:, :, None, None]
+    with torch.enable_grad():
+        wv = w.detach().requires_grad_(True)
+        k = w.shape[2]
+        if mode == PLAIN:
+            out = F.conv2d(xs, wv, padding=k // 2)
+        elif mode == UP2:
+            out = F.conv_transpose2d(xs, wv.transpose(0, 1), stride=2)
+        else:
+            out = F.conv2d(xs, wv, stride=2)
+        (gw,) = torch.autograd.grad(out, wv, g)
+    return gw
+
+
+def modconv(x, w, s=None, demod=None, mode=PLAIN):
+    """x [B,Cin,H,W]; w [Cout,Cin,k,k] (scaled); s [B,Cin] or None; demod [B,Cout] or None."""
+    return ModConvFunction.apply(x, w, s, demod, mode)

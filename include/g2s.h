@@ -111,40 +111,36 @@ int g2s_upfirdn2d(const void *x, const float *k, void *y, int major, int in_h, i
                   int pad_y0, int pad_y1, int dtype, g2s_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * Modulated convolution (StyleGAN2 generator), fp32 MFMA implicit GEMM.
+ * Modulated convolution (StyleGAN2 generator) as an fp32-MFMA implicit GEMM.
  * Replaces the grouped F.conv2d / F.conv_transpose2d inside ModulatedConv2d.forward
- * (stylegan2-pytorch/model.py:250-291) using the input-scaling formulation
- *     y[b,o] = demod[b,o] * sum_{i,ky,kx} Wt[o,i,ky,kx] * (style[b,i] * x[b,i, .+ky, .+kx])
- * which equals the reference's per-sample-weight formulation up to fp32 rounding.
+ * (stylegan2-pytorch/model.py:250-291) and their autograd data-gradients, using the
+ * input-scaling formulation
+ *     y[b,o] = out_scale[b,o] * sum_{i,ky,kx} w[o,i,ky,kx] * (in_scale[b,i] * x[b,i, ...])
+ * (in_scale = modulated style, out_scale = demodulation factor), which equals the reference's
+ * per-sample-weight formulation up to fp32 rounding.
  *
- * mode G2S_CONV_PLAIN : stride 1, zero padding k/2                 (model.py:286-289)
- *      G2S_CONV_UP2   : transposed conv stride 2, padding 0, out = 2*H+1 (model.py:264-274;
- *                       the following Blur is g2s_upfirdn2d)
- *      G2S_CONV_DOWN2 : stride-2 conv, padding 0, out = (H-k)/2+1  (adjoint of UP2; model.py:277-283)
- * x      [B, Cin, H, W] f32
- * w      [Cout, Cin, k, k] f32, already multiplied by the 1/sqrt(fan_in) scale, k in {1,3}
- * style  [B, Cin] f32 or NULL (no modulation)       — multiplies the input channels
- * demod  [B, Cout] f32 or NULL (no demodulation)    — multiplies the output channels
- * y      [B, Cout, Ho, Wo] f32
- * flip_transpose 1: use w as its own adjoint (channels swapped: w is still [Cout_of_fwd, Cin_of_fwd,
- *        k, k], taps flipped) so that bwd-data needs no weight repack:
- *        then x has Cout_of_fwd channels (scaled by `style` == demod of fwd) and y has Cin_of_fwd
- *        channels (scaled by `demod` == style of fwd).
+ * w is always the forward layout [Cout, Cin, k, k] (already multiplied by 1/sqrt(fan_in)).
+ * transpose = 0: x has Cin channels, y has Cout channels, reduction over (i, ky, kx):
+ *   G2S_CONV_PLAIN : y[b,o,Y,X]            = sum x[b,i,Y+ky-k/2,X+kx-k/2] w[o,i,ky,kx]  (model.py:286-289)
+ *   G2S_CONV_UP2   : y[b,o,2y+ky,2x+kx]   += x[b,i,y,x] w[o,i,ky,kx]   out (H-1)*2+k    (model.py:264-274;
+ *                    the Blur that follows is g2s_upfirdn2d)
+ *   G2S_CONV_DOWN2 : y[b,o,Y,X]            = sum x[b,i,2Y+ky,2X+kx] w[o,i,ky,kx]  out (H-k)/2+1 (model.py:277-283)
+ * transpose = 1: the ADJOINT of the same mode's transpose=0 map w.r.t. x — x has Cout channels,
+ *   y has Cin channels, reduction over (o, ky, kx), no weight repacking:
+ *   G2S_CONV_PLAIN : y[b,i,Y,X]            = sum x[b,o,Y-ky+k/2,X-kx+k/2] w[o,i,ky,kx]
+ *   G2S_CONV_DOWN2 : y[b,i,2Y+ky,2X+kx]   += x[b,o,Y,X] w[o,i,ky,kx]            (adjoint of DOWN2)
+ *   G2S_CONV_UP2   : y[b,i,Y,X]            = sum x[b,o,2Y+ky,2X+kx] w[o,i,ky,kx] (adjoint of UP2;
+ *                    here H, W are the sizes of x and must be odd: out (H-k)/2+1)
+ * x [B, C_in_of_this_call, H, W] f32; in_scale [B, C_in_of_this_call] or NULL;
+ * out_scale [B, C_out_of_this_call] or NULL; y fully overwritten.  k in {1, 3} (1 only PLAIN).
  * ---------------------------------------------------------------------------------------- */
 #define G2S_CONV_PLAIN 0
 #define G2S_CONV_UP2 1
 #define G2S_CONV_DOWN2 2
 
-int g2s_modconv(const float *x, const float *w, const float *style, const float *demod, float *y,
-                int B, int Cin, int Cout, int H, int W, int k, int mode, int flip_transpose,
+int g2s_modconv(const float *x, const float *w, const float *in_scale, const float *out_scale,
+                float *y, int B, int Cin, int Cout, int H, int W, int k, int mode, int transpose,
                 g2s_stream_t stream);
-
-/* demod[b,o] = rsqrt( sum_i (sum_{ky,kx} w[o,i,ky,kx]^2) * style[b,i]^2 + eps )
- * (model.py:256-258 with weight = scale*W*style).  wsq [Cout, Cin] = sum over taps of w^2 is
- * produced by g2s_modconv_wsq. */
-int g2s_modconv_wsq(const float *w, float *wsq, int Cout, int Cin, int k, g2s_stream_t stream);
-int g2s_modconv_demod(const float *wsq, const float *style, float *demod, int B, int Cin, int Cout,
-                      float eps, g2s_stream_t stream);
 
 #ifdef __cplusplus
 }

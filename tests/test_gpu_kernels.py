@@ -1,0 +1,282 @@
+"""-m gpu parity tests: the HIP kernels (through the C ABI of libg2s.so) against the CPU oracle and
+the golden vectors generated from the reference's own Python.
+
+Tolerances: integer/index outputs (face ids) bit-exact; rasterizer floats bit-exact against the
+fp32 oracle (same operation order, no FMA contraction); elementwise ops exact or 1 ulp;
+convolutions / FIR within 1e-5 relative of the fp32 reference (summation order differs)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import capi  # noqa: E402
+from oracle import geometry as og  # noqa: E402
+from raster_cases import scene, soup  # noqa: E402
+
+FAR = 100.0
+
+
+@pytest.fixture(scope="module")
+def g2s():
+    import gan2shape_amd  # noqa: F401
+    from gan2shape_amd import lib
+    lib.load()  # fails loudly if libg2s.so is missing
+    assert torch.cuda.is_available()
+    return gan2shape_amd
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+# ----------------------------------------------------------------------------- fused_bias_act
+@pytest.mark.parametrize("name", ["4d", "2d"])
+def test_fused_leaky_relu_golden(g2s, golden, name):
+    from gan2shape_amd.op import fused_leaky_relu
+    g = golden("ops")
+    x = dev(g[f"fused.{name}.x"]).requires_grad_(True)
+    b = dev(g[f"fused.{name}.b"]).requires_grad_(True)
+    y = fused_leaky_relu(x, b)
+    gx, gb = torch.autograd.grad(y, (x, b), dev(g[f"fused.{name}.gy"]))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"fused.{name}.y"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(gx.cpu().numpy(), g[f"fused.{name}.gx"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(gb.cpu().numpy(), g[f"fused.{name}.gb"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 32, 32), (3, 5, 7, 9), (4, 512), (1, 3, 1, 1)])
+@pytest.mark.parametrize("act,grad", [(3, 0), (3, 1), (1, 0), (3, 2), (7, 0)])
+def test_fused_bias_act_vs_oracle(g2s, shape, act, grad):
+    from gan2shape_amd.plugins import fused
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(shape).astype(np.float32)
+    b = rng.standard_normal(shape[1]).astype(np.float32)
+    ref = rng.standard_normal(shape).astype(np.float32)
+    for use_b in (True, False):
+        exp = capi.fused_bias_act(x, b if use_b else None, ref if grad == 1 else None, act, grad, 0.2, 1.4142135)
+        empty = torch.empty(0, device="cuda")
+        y = fused.fused_bias_act(dev(x), dev(b) if use_b else empty, dev(ref) if grad == 1 else empty,
+                                 act, grad, 0.2, 1.4142135)
+        np.testing.assert_array_equal(y.cpu().numpy(), exp)
+
+
+def test_fused_bias_act_f16_and_errors(g2s):
+    from gan2shape_amd.plugins import fused
+    x = torch.randn(2, 4, 6, 6, device="cuda").half()
+    b = torch.randn(4, device="cuda").half()
+    y = fused.fused_bias_act(x, b, x.new_empty(0), 3, 0, 0.2, 2 ** 0.5)
+    exp = torch.nn.functional.leaky_relu((x + b.view(1, -1, 1, 1)).float(), 0.2) * 2 ** 0.5
+    torch.testing.assert_close(y.float(), exp, rtol=2e-3, atol=2e-3)
+    with pytest.raises(RuntimeError):
+        fused.fused_bias_act(x.cpu(), b, x.new_empty(0), 3, 0, 0.2, 1.0)  # CHECK_CUDA
+
+
+def test_noise_bias_act(g2s):
+    from gan2shape_amd.op import fused_noise_bias_act
+    torch.manual_seed(0)
+    for shape in [(2, 8, 16, 16), (2, 5, 3, 3)]:
+        x = torch.randn(*shape, device="cuda", requires_grad=True)
+        noise = torch.randn(1, 1, *shape[2:], device="cuda")
+        nw = torch.randn(1, device="cuda")
+        b = torch.randn(shape[1], device="cuda")
+        y = fused_noise_bias_act(x, noise, nw, b)
+        exp = 2 ** 0.5 * torch.nn.functional.leaky_relu(x + nw * noise + b.view(1, -1, 1, 1), 0.2)
+        torch.testing.assert_close(y, exp, rtol=1e-6, atol=1e-6)
+        gy = torch.randn_like(y)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        (gexp,) = torch.autograd.grad(exp, x, gy)
+        torch.testing.assert_close(gx, gexp, rtol=1e-6, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- upfirdn2d
+UP_CASES = ["blur_up", "rgb_up", "d_blur3", "d_blur1", "down2", "crop"]
+
+
+@pytest.mark.parametrize("name", UP_CASES)
+def test_upfirdn2d_golden(g2s, golden, name):
+    from gan2shape_amd.op import upfirdn2d
+    g = golden("ops")
+    up, down, p0, p1 = (int(v) for v in g[f"upfirdn2d.{name}.args"])
+    x = dev(g[f"upfirdn2d.{name}.x"]).requires_grad_(True)
+    y = upfirdn2d(x, dev(g[f"upfirdn2d.{name}.k"]), up=up, down=down, pad=(p0, p1))
+    (gx,) = torch.autograd.grad(y, x, dev(g[f"upfirdn2d.{name}.gy"]))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"upfirdn2d.{name}.y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gx.cpu().numpy(), g[f"upfirdn2d.{name}.gx"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,up,down,pad", [
+    ((2, 16, 65, 65), 1, 1, (1, 1)),     # G blur after up-conv
+    ((2, 3, 32, 32), 2, 1, (2, 1)),      # ToRGB skip upsample
+    ((2, 8, 64, 64), 1, 1, (2, 2)),      # D blur before 3x3 s2
+    ((2, 8, 33, 47), 1, 2, (1, 1)),      # downsample, ragged
+    ((1, 2, 5, 3), 1, 1, (2, 2)),        # smaller than a tile
+    ((1, 1, 40, 40), 3, 2, (2, 3)),      # generic fallback path
+])
+def test_upfirdn2d_vs_oracle(g2s, shape, up, down, pad):
+    from gan2shape_amd.op import upfirdn2d
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(shape).astype(np.float32)
+    k = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32)
+    k = k / k.sum() * up * up + 0.01 * rng.standard_normal((4, 4)).astype(np.float32)  # asymmetric
+    exp = capi.upfirdn2d(x, k, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+    y = upfirdn2d(dev(x), dev(k), up=up, down=down, pad=pad)
+    np.testing.assert_allclose(y.cpu().numpy(), exp, rtol=1e-5, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- rasterizer
+def _render(verts, faces, S, K, ssaa=2, fill_back=True, implicit=False, grad=None):
+    from gan2shape_amd.plugins import neural_renderer as nr
+    v = dev(verts).requires_grad_(grad is not None)
+    f = None if implicit else dev(faces, torch.int32)
+    d = nr.RenderDepthFunction.apply(v, f, tuple(np.asarray(K, np.float32).reshape(9).tolist()),
+                                     float(S), S, ssaa == 2, fill_back, 0.1, FAR)
+    if grad is None:
+        return d.cpu().numpy()
+    (gv,) = torch.autograd.grad(d, v, dev(grad))
+    return d.detach().cpu().numpy(), gv.cpu().numpy()
+
+
+@pytest.mark.parametrize("S,ssaa,fill_back,implicit", [
+    (16, 2, True, True), (16, 2, True, False), (20, 2, True, True), (32, 2, True, True),
+    (16, 1, True, True), (16, 2, False, True), (12, 1, False, False), (36, 2, True, True)])
+def test_raster_forward_bit_exact(g2s, S, ssaa, fill_back, implicit):
+    geo, verts, faces = scene(S, B=2, seed=S + ssaa)
+    ref = capi.render_depth(verts, faces, S, geo.K[0], ssaa=ssaa, fill_back=fill_back, far=FAR)
+    d = _render(verts, faces, S, geo.K[0], ssaa, fill_back, implicit)
+    np.testing.assert_array_equal(d, ref["depth"])
+
+
+def test_raster_saved_maps_and_backward(g2s):
+    from gan2shape_amd import lib
+    S = 32
+    geo, verts, faces = scene(S, B=2, seed=5)
+    ref = capi.render_depth(verts, faces, S, geo.K[0], far=FAR)
+    rng = np.random.default_rng(0)
+    g = rng.standard_normal((2, S, S)).astype(np.float32)
+    g[ref["depth"] > 1.2] = 0
+    gref = capi.render_depth_bwd(verts.astype(np.float64), faces, g.astype(np.float64),
+                                 ref["face_idx"], ref["bary"].astype(np.float64), S,
+                                 geo.K[0].astype(np.float64), dtype=np.float64)
+    scale = np.abs(gref).max()
+    for implicit in (True, False):
+        d, gv = _render(verts, faces, S, geo.K[0], implicit=implicit, grad=g)
+        np.testing.assert_array_equal(d, ref["depth"])
+        np.testing.assert_allclose(gv, gref, atol=3e-5 * scale)
+    # the saved maps themselves (index work: bit-exact)
+    L = lib.load()
+    v = dev(verts)
+    depth = torch.empty(2, S, S, device="cuda")
+    fidx = torch.empty(2, 2 * S, 2 * S, dtype=torch.int32, device="cuda")
+    bary = torch.empty(2, 2 * S, 2 * S, 3, device="cuda")
+    ws = torch.empty(L.g2s_raster_workspace_bytes(2, S * S, faces.shape[0], S), dtype=torch.uint8, device="cuda")
+    Kc = (lib.C.c_float * 9)(*np.asarray(geo.K[0], np.float32).reshape(9).tolist())
+    lib.check(L.g2s_raster_depth_fwd(lib.ptr(v), None, 2, S * S, faces.shape[0], S, Kc, float(S), 2, 1,
+                                     0.1, FAR, lib.ptr(depth), lib.ptr(fidx), lib.ptr(bary), lib.ptr(ws),
+                                     ws.numel(), lib.stream()))
+    np.testing.assert_array_equal(fidx.cpu().numpy(), ref["face_idx"])
+    np.testing.assert_array_equal(bary.cpu().numpy(), ref["bary"])
+
+
+def test_raster_triangle_soup(g2s):
+    verts, faces = soup(n_faces=700, n_verts=300)
+    S = 24
+    K = og.Geometry(S).K[0]
+    for fill_back in (True, False):
+        ref = capi.render_depth(verts, faces, S, K, fill_back=fill_back, far=FAR)
+        d = _render(verts, faces, S, K, 2, fill_back, implicit=False)
+        np.testing.assert_array_equal(d, ref["depth"])
+
+
+def test_raster_full_size_properties(g2s):
+    """S = 128 (BASELINE face config), B = 8: properties that need no brute-force oracle."""
+    S, B = 128, 8
+    geo = og.Geometry(S)
+    fx, cx = geo.K[0, 0, 0], geo.K[0, 0, 2]
+    v, u = np.meshgrid(np.arange(S), np.arange(S), indexing="ij")
+
+    def plane(uu, vv, a, b):
+        return 1.0 / (1 - a * (uu - cx) / fx - b * (vv - cx) / fx)
+
+    coef = [(0.0, 0.0), (0.5, -0.3), (-0.8, 0.2), (0.1, 0.9), (0, 0), (0.3, 0.3), (-0.2, -0.6), (0.7, 0.1)]
+    depth = np.stack([plane(u, v, a, b) for a, b in coef]).astype(np.float32)
+    geo.set_transform_matrices(np.zeros((B, 6), np.float32))
+    verts = geo.get_warped_3d_grid(depth).reshape(B, -1, 3)
+    faces = og.get_face_idx(1, S, S)[0]
+    d = _render(verts, faces, S, geo.K[0], implicit=True)
+    for i, (a, b) in enumerate(coef):
+        exp = sum(plane(u + dc, v + dr, a, b) for dr in (.25, .75) for dc in (.25, .75)) / 4
+        np.testing.assert_allclose(d[i, :S - 1, :S - 1], exp[:S - 1, :S - 1], rtol=3e-5)
+    np.testing.assert_array_equal(d[:, S - 1, :], FAR)
+    np.testing.assert_array_equal(d[:, :, S - 1], FAR)
+    # explicit topology gives the same image as the implicit one, batch entries are independent
+    geo2, verts2, _ = scene(S, B=B, seed=11)
+    d_imp = _render(verts2, faces, S, geo2.K[0], implicit=True)
+    d_exp = _render(verts2, faces, S, geo2.K[0], implicit=False)
+    np.testing.assert_array_equal(d_imp, d_exp)
+    d_one = _render(verts2[3:4], faces, S, geo2.K[0], implicit=True)
+    np.testing.assert_array_equal(d_one[0], d_imp[3])
+    assert ((d_imp > 0.8) & (d_imp < 1.2)).mean() > 0.5
+
+
+# ----------------------------------------------------------------------------- modulated conv
+def _style_mod(g, name):
+    w, b, s = g[f"{name}.mod_weight"], g[f"{name}.mod_bias"], g[f"{name}.s"]
+    return (s @ (w * (1 / math.sqrt(w.shape[1]))).T + b).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["plain", "up", "rgb", "down"])
+def test_modulated_conv_golden(g2s, golden, name):
+    """Module-level parity with the reference's ModulatedConv2d (outputs and gradients w.r.t.
+    input and style) on the fixtures generated by tests/golden/make_golden.py."""
+    from gan2shape_amd import stylegan2 as sg2
+    g = golden("modconv")
+    cout, cin, k = g[f"{name}.weight"].shape[1:4]
+    kw = dict(plain={}, up=dict(upsample=True), rgb=dict(demodulate=False), down=dict(downsample=True))[name]
+    m = sg2.ModulatedConv2d(cin, cout, k, 16, **kw).cuda()
+    with torch.no_grad():
+        m.weight.copy_(dev(g[f"{name}.weight"]))
+        m.modulation.weight.copy_(dev(g[f"{name}.mod_weight"]))
+        m.modulation.bias.copy_(dev(g[f"{name}.mod_bias"]))
+    x = dev(g[f"{name}.x"]).requires_grad_(True)
+    s = dev(g[f"{name}.s"]).requires_grad_(True)
+    y = m(x, s)
+    gx, gs, gw = torch.autograd.grad(y, (x, s, m.weight), dev(g[f"{name}.gy"]))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{name}.y"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(gx.cpu().numpy(), g[f"{name}.gx"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(gs.cpu().numpy(), g[f"{name}.gs"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(gw.cpu().numpy(), g[f"{name}.gw"], rtol=1e-3, atol=5e-5)
+
+
+@pytest.mark.parametrize("B,cin,cout,h,k,mode", [
+    (2, 64, 96, 16, 3, 0), (3, 40, 130, 9, 3, 0), (2, 64, 64, 8, 3, 1), (2, 32, 48, 13, 3, 2),
+    (2, 128, 3, 32, 1, 0), (8, 512, 512, 4, 3, 0), (2, 256, 128, 16, 3, 1), (1, 8, 8, 5, 3, 1)])
+def test_modconv_vs_oracle(g2s, B, cin, cout, h, k, mode):
+    from gan2shape_amd.modconv import modconv_raw
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((B, cin, h, h)).astype(np.float32)
+    w = rng.standard_normal((cout, cin, k, k)).astype(np.float32)
+    s = (1 + 0.3 * rng.standard_normal((B, cin))).astype(np.float32)
+    scale = 1 / math.sqrt(cin * k * k)
+    exp = capi.modconv(x, w, s, scale, True, mode)
+    ws = w * scale
+    demod = 1 / np.sqrt((s[:, None, :] ** 2 * (ws ** 2).sum((2, 3))[None]).sum(2) + 1e-8)
+    y = modconv_raw(dev(x), dev(ws), dev(s), dev(demod), mode, 0)
+    np.testing.assert_allclose(y.cpu().numpy(), exp, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("mode,h", [(0, 12), (1, 7), (2, 11)])
+def test_modconv_transpose_is_adjoint(g2s, mode, h):
+    """<conv(x), g> == <x, conv^T(g)> for every geometry (the data-gradient kernel)."""
+    from gan2shape_amd.modconv import modconv_raw
+    torch.manual_seed(0)
+    B, cin, cout = 2, 24, 40
+    x = torch.randn(B, cin, h, h, device="cuda")
+    w = torch.randn(cout, cin, 3, 3, device="cuda") / 10
+    y = modconv_raw(x, w, None, None, mode, 0)
+    g = torch.randn_like(y)
+    xt = modconv_raw(g, w, None, None, mode, 1)
+    assert xt.shape == x.shape
+    lhs, rhs = (y.double() * g.double()).sum().item(), (x.double() * xt.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
