@@ -1,0 +1,230 @@
+"""GAN2Shape training-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload = "face128_n8"): configs/face.yml restated for the offline box — image
+128x128, StyleGAN2 size 128 / channel_multiplier 1 / z_dim 512, n_proj_samples 8, ellipsoid-prior
+depth, random-init weights, synthetic image + latent (seed 1234 + rank), synthetic view/light
+distributions.  One bench "step" = ONE training iteration (zero_grad, forward_stepK, backward,
+Adam.step) exactly as GAN2Shape/trainer.py:99-109 runs it; the step kinds cycle in the stage-0
+ratio of main.py:148 (700:700:600 = 7:7:6): seven step-1, seven step-2, six step-3 iterations per
+20 steps, each kind handing its `collected` to the next as the trainer does.  The reported value is
+therefore the stage-0-weighted aggregate  iterations / second.
+
+Multi-GPU: the per-image optimisation is independent, so each rank trains its own image with its
+own model replica and optimisers; no data-path collective (weak scaling).  value = N * K / T with T
+the max over ranks of the barrier-bracketed wall time.
+
+Also reported on the same JSON line: `roofline` of the dominant custom kernel (the fp32-MFMA
+modulated-convolution GEMM: algorithmic FLOP / HIP-event time on the launch stream, against the
+157.3 TFLOP/s fp32 matrix peak) and `cpu_baseline` (the CPU oracle's restatement of the native hot
+ops timed on this box's host cores on a bounded sample and scaled to iterations/second).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PATTERN = [1] * 7 + [2] * 7 + [3] * 6   # main.py:148 stage 0 = {700, 700, 600}
+F32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def face_config(n_proj=8):
+    return {
+        'image_size': 128, 'z_dim': 512, 'gan_size': 128, 'channel_multiplier': 1,
+        'gan_ckpt_path': None, 'n_proj_samples': n_proj, 'category': 'face',
+        'prior_name': 'ellipsoid', 'n_epochs_prior': 0, 'learning_rate': 1e-4, 'view_scale': 1,
+        'rot_center_depth': 1.0, 'fov': 10, 'tex_cube_size': 2,
+        'view_mvn_path': None, 'light_mvn_path': None,
+        # SURVEY.md §8d synthetic distributions
+        'view_mvn': {'mean': [0.] * 6,
+                     'cov': [[v * v if i == j else 0. for j in range(6)]
+                             for i, v in enumerate([.05, .15, .03, .05, .05, .05])]},
+        'light_mvn': {'mean': [0.] * 4,
+                      'cov': [[0.01 if i == j else 0. for j in range(4)] for i in range(4)]},
+    }
+
+
+def synthetic_sample(model, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(1, 3, 32, 32, generator=g)
+    img = torch.tanh(torch.nn.functional.interpolate(img, scale_factor=4, mode='bilinear')).to(device)
+    with torch.no_grad():
+        w = model.generator.style_forward(torch.randn(1, 512, generator=g).to(device))
+    return img, w
+
+
+class StepRunner:
+    """Runs training iterations in the trainer's order, keeping `collected` between kinds."""
+
+    def __init__(self, trainer, image, latent):
+        self.t, self.image, self.latent = trainer, image, latent
+        self.collected = {1: None, 2: None, 3: None}
+        self.kind_ms = {1: [], 2: [], 3: []}
+
+    def run(self, kind, timed=False):
+        t = self.t
+        optim = getattr(t, f'optim_step{kind}')
+        src = {1: None, 2: self.collected[1], 3: self.collected[2]}[kind]
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        optim.zero_grad()
+        loss, collected = getattr(t.model, f'forward_step{kind}')(
+            self.image, self.latent, src, n_proj_samples=t.n_proj_samples)
+        loss.backward()
+        optim.step()
+        if timed:
+            e1.record()
+            self.kind_ms[kind].append((e0, e1))
+        self.collected[kind] = collected
+        return loss
+
+
+def cpu_baseline(n_proj):
+    """Oracle ("port") timings of the native hot ops on the host cores, bounded to ~10-30 s, scaled
+    to aggregate iterations / second.  Covers the custom-kernel share of an iteration only (the
+    modulated convolutions of the generator pass and the rasterizer), so it over-states CPU speed."""
+    import numpy as np
+    from oracle import capi
+    from oracle import geometry as og
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    rng = np.random.default_rng(0)
+    # (a) one modulated conv, 128 -> 128 channels at 64x64, B = 1: 2*128*128*9*4096 = 1.2 GFLOP
+    x = rng.standard_normal((1, 128, 64, 64)).astype(np.float32)
+    w = rng.standard_normal((128, 128, 3, 3)).astype(np.float32)
+    s = np.ones((1, 128), np.float32)
+    capi.modconv(x[:, :, :8, :8], w, s, 1.0, True, 0)
+    t0 = time.perf_counter()
+    capi.modconv(x, w, s, 1.0, True, 0)
+    t_conv = time.perf_counter() - t0
+    gflop_sample = 2 * 128 * 128 * 9 * 64 * 64 / 1e9
+    # generator forward 22.52 GFLOP / image, forward + data-gradient, n_proj images
+    gflop_step2 = 22.52 * n_proj * 2
+    t_step2 = t_conv * gflop_step2 / gflop_sample
+    # (b) brute-force rasterizer (the reference algorithm), one 128x128 image
+    S = 128
+    geo = og.Geometry(S)
+    geo.set_transform_matrices(np.array([[0.2, -0.3, 0.05, 0.01, 0.02, -0.03]], np.float32))
+    depth = (1.0 + 0.05 * np.sin(np.arange(S)[None, :, None] / 9.0) * np.ones((1, S, S))).astype(np.float32)
+    verts = geo.get_warped_3d_grid(depth).reshape(1, -1, 3)
+    faces = og.get_face_idx(1, S, S)[0]
+    t0 = time.perf_counter()
+    capi.render_depth(verts, faces, S, geo.K[0])
+    t_raster = time.perf_counter() - t0
+    # rasterized images per iteration: step 1: 1, step 2: n, step 3: 1 + n
+    t1, t2, t3 = t_raster, t_step2 + n_proj * t_raster, (1 + n_proj) * t_raster
+    its = 20.0 / (7 * t1 + 7 * t2 + 6 * t3)
+    return {"value": its, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"oracle modconv 128->128@64x64 B=1 ({t_conv:.2f}s, scaled by GFLOP to the "
+                      f"generator fwd+bwd of step 2) + brute-force raster of one 128x128 image "
+                      f"({t_raster:.2f}s, scaled by images/iteration); custom-kernel share only"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n-proj", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import gan2shape_amd  # noqa: F401
+    from gan2shape_amd import lib, modconv as mc
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import Trainer
+    lib.load()
+
+    torch.manual_seed(0)  # identical random-init weights on every rank
+    cfg = face_config(args.n_proj)
+    trainer = Trainer(GAN2Shape, cfg, device=device)
+    image, latent = synthetic_sample(trainer.model, 1234 + rank, device)
+    torch.manual_seed(1234 + rank)
+    runner = StepRunner(trainer, image, latent)
+
+    # setup pass (not a benchmark step): one iteration of each kind creates the `collected`
+    # hand-offs the trainer would have at this point, and triggers lazy library initialisation
+    for kind in (1, 2, 3):
+        runner.run(kind)
+    for i in range(args.warmup):
+        runner.run(PATTERN[i % len(PATTERN)])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    mc.PROFILE = []  # (flops, start event, end event) per g2s_modconv launch, on its stream
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        runner.run(PATTERN[i % len(PATTERN)], timed=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, mc.PROFILE = mc.PROFILE, None
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        kind_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None)
+                   for k, v in runner.kind_ms.items()}
+        flops = sum(p[0] for p in prof)
+        ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "kernel": "g2s::modconv_kernel (fp32 MFMA implicit GEMM)",
+                    "launches": len(prof), "avg_launch_us": (ms * 1e3 / len(prof)) if prof else None,
+                    "gflop_per_launch": (flops / 1e9 / len(prof)) if prof else None,
+                    "share_of_timed_region": ms * 1e-3 / elapsed}
+        out = {
+            "metric": "GAN2Shape step iters/sec, faces 128x128 b=8",
+            "value": world * args.steps / elapsed, "unit": "iters/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "face128_n8" if args.n_proj == 8 else f"face128_n{args.n_proj}",
+                       "image_size": 128, "gan_size": 128, "n_proj_samples": args.n_proj,
+                       "step_mix": "7:7:6 (step1:step2:step3, main.py:148 stage 0)",
+                       "images_per_rank": 1, "sharding": "one image per rank, no collective"},
+            "ms_per_step_kind": {f"step{k}": v for k, v in kind_ms.items()},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.n_proj)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+"""LPIPS-VGG perceptual loss, restated from the vendored lpips package of the reference
+(GAN2Shape/stylegan2/stylegan2-pytorch/lpips/__init__.py:12-39 PerceptualLoss,
+networks_basic.py:27-110 PNetLin / ScalingLayer / NetLinLayer, pretrained_networks.py:97-135 vgg16,
+__init__.py:40-42 normalize_tensor).  Plain torch on MIOpen: inside every
+step-1/3 iteration, but not a custom-kernel target.
+
+State-dict keys equal the reference's PNetLin (`net.slice{1..5}.<torchvision index>.weight`,
+`lin{0..4}.model.1.weight`), so `lpips/weights/v0.1/vgg.pth` (5 tensors) and a torchvision VGG16
+`features` state dict load unchanged through `load_lin_weights` / `load_vgg_features`.  torchvision
+and its pretrained download are unavailable offline: without those files the network is
+random-initialised (benchmarks / tests), and says so via `.pretrained`.
+"""
+import torch
+import torch.nn as nn
+
+# torchvision.models.vgg16().features layout: conv indices and the pools in front of each slice
+_VGG_SLICES = [
+    [(0, 3, 64), (2, 64, 64)],
+    [(5, 64, 128), (7, 128, 128)],
+    [(10, 128, 256), (12, 256, 256), (14, 256, 256)],
+    [(17, 256, 512), (19, 512, 512), (21, 512, 512)],
+    [(24, 512, 512), (26, 512, 512), (28, 512, 512)],
+]
+_POOL_BEFORE = [None, 4, 9, 16, 23]
+
+
+def normalize_tensor(in_feat, eps=1e-10):
+    norm_factor = torch.sqrt(torch.sum(in_feat ** 2, dim=1, keepdim=True))
+    return in_feat / (norm_factor + eps)
+
+
+class VGG16Features(nn.Module):
+    """relu1_2, relu2_2, relu3_3, relu4_3, relu5_3 (pretrained_networks.py:97-135)."""
+
+    def __init__(self):
+        super().__init__()
+        for si, convs in enumerate(_VGG_SLICES):
+            seq = nn.Sequential()
+            if _POOL_BEFORE[si] is not None:
+                seq.add_module(str(_POOL_BEFORE[si]), nn.MaxPool2d(kernel_size=2, stride=2))
+            for idx, cin, cout in convs:
+                seq.add_module(str(idx), nn.Conv2d(cin, cout, kernel_size=3, padding=1))
+                seq.add_module(str(idx + 1), nn.ReLU(inplace=True))
+            setattr(self, f"slice{si + 1}", seq)
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        outs = []
+        for si in range(5):
+            x = getattr(self, f"slice{si + 1}")(x)
+            outs.append(x)
+        return outs
+
+
+class ScalingLayer(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer('shift', torch.Tensor([-.030, -.088, -.188])[None, :, None, None])
+        self.register_buffer('scale', torch.Tensor([.458, .448, .450])[None, :, None, None])
+
+    def forward(self, inp):
+        return (inp - self.shift) / self.scale
+
+
+class NetLinLayer(nn.Module):
+    def __init__(self, chn_in, chn_out=1, use_dropout=True):
+        super().__init__()
+        layers = [nn.Dropout()] if use_dropout else []
+        layers += [nn.Conv2d(chn_in, chn_out, 1, stride=1, padding=0, bias=False)]
+        self.model = nn.Sequential(*layers)
+
+
+class PNetLin(nn.Module):
+    """networks_basic.py:27-92 for pnet_type='vgg', lpips=True, spatial=False, version 0.1."""
+
+    def __init__(self):
+        super().__init__()
+        self.scaling_layer = ScalingLayer()
+        self.chns = [64, 128, 256, 512, 512]
+        self.net = VGG16Features()
+        for i, c in enumerate(self.chns):
+            setattr(self, f"lin{i}", NetLinLayer(c))
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def features(self, x):
+        return [normalize_tensor(f) for f in self.net(self.scaling_layer(x))]
+
+    def forward(self, in0, in1):
+        f0, f1 = self.features(in0), self.features(in1)
+        val = 0
+        for k in range(5):
+            diff = (f0[k] - f1[k]) ** 2
+            val = val + getattr(self, f"lin{k}").model(diff).mean([2, 3], keepdim=True)
+        return val
+
+
+class PerceptualLoss(nn.Module):
+    """PerceptualLoss(model='net-lin', net='vgg') as constructed at GAN2Shape/model.py:79-81.
+    forward(pred, target) -> (N, 1, 1, 1); the reference calls model.forward(target, pred)
+    (lpips/__init__.py:39) — the metric is symmetric."""
+
+    def __init__(self, model='net-lin', net='vgg', use_gpu=True, gpu_ids=None,
+                 lin_weights_path=None, vgg_weights_path=None):
+        super().__init__()
+        if model != 'net-lin' or net != 'vgg':
+            raise NotImplementedError("only model='net-lin', net='vgg' (GAN2Shape/model.py:79)")
+        self.net = PNetLin()
+        self.pretrained = False
+        if lin_weights_path is not None:
+            self.load_lin_weights(lin_weights_path)
+        if vgg_weights_path is not None:
+            self.load_vgg_features(vgg_weights_path)
+            self.pretrained = lin_weights_path is not None
+        self.net.eval()
+
+    def load_lin_weights(self, path):
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        missing = self.net.load_state_dict(sd, strict=False)
+        assert not [k for k in missing.unexpected_keys if k.startswith("lin")], missing
+
+    def load_vgg_features(self, path):
+        """A torchvision vgg16 state dict ('features.<idx>.weight') or its `.features` sub-dict."""
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        sd = {k.replace("features.", ""): v for k, v in sd.items() if "classifier" not in k}
+        own = {}
+        for si, convs in enumerate(_VGG_SLICES):
+            for idx, _, _ in convs:
+                for suffix in ("weight", "bias"):
+                    own[f"slice{si + 1}.{idx}.{suffix}"] = sd[f"{idx}.{suffix}"]
+        self.net.net.load_state_dict(own)
+
+    def forward(self, pred, target, normalize=False):
+        if normalize:
+            target = 2 * target - 1
+            pred = 2 * pred - 1
+        return self.net(target, pred)

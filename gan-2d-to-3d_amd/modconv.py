@@ -19,6 +19,10 @@ from . import lib as _lib
 
 PLAIN, UP2, DOWN2 = _lib.CONV_PLAIN, _lib.CONV_UP2, _lib.CONV_DOWN2
 
+# bench.py sets this to a list to collect (algorithmic FLOP, start event, end event) per launch,
+# recorded on the launch stream; None = no instrumentation.
+PROFILE = None
+
 
 def out_size(h, k, mode):
     if mode == PLAIN:
@@ -54,8 +58,17 @@ def modconv_raw(x, w, in_scale, out_scale, mode, transpose):
     si = None if in_scale is None else in_scale.contiguous()
     so = None if out_scale is None else out_scale.contiguous()
     L = _lib.load()
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(L.g2s_modconv(_lib.ptr(x), _lib.ptr(w), _lib.ptr(si), _lib.ptr(so), _lib.ptr(y), B,
                              Cin, Cout, H, W, k, mode, int(transpose), _lib.stream()))
+    if prof is not None:
+        e1.record()
+        # algorithmic FLOP: 2 * B * Cout * Cin * k^2 * (spatial positions of the un-strided side)
+        sp = min(H * W, oh * ow) if mode != PLAIN else oh * ow
+        prof.append((2.0 * B * Cout * Cin * k * k * sp, e0, e1))
     return y
 
 

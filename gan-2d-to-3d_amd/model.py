@@ -1,0 +1,399 @@
+"""GAN2Shape model: the three training steps on the MI355X-native kernels.
+
+Host-side mirror of GAN2Shape/model.py:18-470 — same constructor `GAN2Shape(config, debug)`, the
+step API the trainer calls through getattr (trainer.py:103-104)
+`forward_step{1,2,3}(images, latents, collected, n_proj_samples=...) -> (loss, collected)`,
+`depth_net_forward`, `evaluate_results`, checkpoint helpers, and the attributes the optimisers are
+built from (`albedo_net`, `offset_encoder_net`, `lighting_net`, `viewpoint_net`, `depth_net`).
+
+Conscious differences (none changes a returned value):
+  * `device` argument instead of hard-coded .cuda() (model.py:33-46,81);
+  * step 2's `collected` stays on the device (the reference round-trips it through the CPU every
+    iteration, model.py:222,234);
+  * dead work is dropped: `recon_normal` (model.py:142), the `gan_im` generator pass when
+    `relative_encoding` is False (:193-200), generator / discriminator weight gradients (G and D
+    are frozen; their parameters get requires_grad=False);
+  * `center_w` / `center_h` (:201-203) are constants of the frozen generator and computed once;
+  * every grid_sample passes align_corners=True (torch-1.2 semantics the reference relies on);
+  * offline: a missing `gan_ckpt_path` / `view_mvn_path` / `light_mvn_path` falls back to
+    random-init G/D and to the `view_mvn` / `light_mvn` entries of the config (mean, cov lists).
+"""
+import datetime
+import logging
+import math
+import os
+from glob import glob
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.distributions.multivariate_normal import MultivariateNormal
+
+from . import networks, utils
+from .losses import DiscriminatorLoss, PhotometricLoss, SmoothLoss
+from .lpips import PerceptualLoss
+from .renderer import Renderer
+from .stylegan2 import Discriminator, Generator
+
+
+class GAN2Shape(nn.Module):
+    NETS = ['lighting', 'viewpoint', 'depth', 'albedo', 'offset_encoder']
+
+    def __init__(self, config, debug=False, device="cuda"):
+        super().__init__()
+        self.device = torch.device(device)
+        self.z_dim = config.get('z_dim')
+        self.debug = debug
+        # frozen StyleGAN2 pair (model.py:26-37)
+        self.generator = Generator(config.get('gan_size'), self.z_dim, 8,
+                                   channel_multiplier=config.get('channel_multiplier'))
+        self.discriminator = Discriminator(config.get('gan_size'),
+                                           channel_multiplier=config.get('channel_multiplier'))
+        ckpt_path = config.get('gan_ckpt_path')
+        self.gan_pretrained = bool(ckpt_path) and os.path.exists(ckpt_path)
+        if self.gan_pretrained:
+            gan_ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+            self.generator.load_state_dict(gan_ckpt['g_ema'], strict=False)
+            self.discriminator.load_state_dict(gan_ckpt['d'], strict=False)
+        else:
+            logging.warning("gan_ckpt_path %r not found: random-initialised StyleGAN2", ckpt_path)
+        self.generator = self.generator.to(self.device).eval().requires_grad_(False)
+        self.discriminator = self.discriminator.to(self.device).eval().requires_grad_(False)
+
+        self.image_size = config.get('image_size')
+        self.collected = None
+
+        self.lighting_net = networks.LightingNet(self.image_size, self.debug).to(self.device)
+        self.viewpoint_net = networks.ViewpointNet(self.image_size, self.debug).to(self.device)
+        self.depth_net = networks.DepthNet(self.image_size, self.debug).to(self.device)
+        self.albedo_net = networks.AlbedoNet(self.image_size, self.debug).to(self.device)
+        self.offset_encoder_net = networks.OffsetEncoder(self.image_size, debug=self.debug).to(self.device)
+
+        # Misc (model.py:48-66)
+        self.max_depth = 1.1
+        self.min_depth = 0.9
+        self.border_depth = 0.7 * self.max_depth + 0.3 * self.min_depth
+        self.lam_perc = 1
+        self.lam_smooth = 0.01
+        self.lam_regular = 0.01
+        self.xyz_rotation_range = config.get('xyz_rotation_range', 60)
+        self.xy_translation_range = config.get('xy_translation_range', 0.1)
+        self.z_translation_range = config.get('z_translation_range', 0.1)
+        self.use_mask = config.get('use_mask', True)
+        self.relative_encoding = config.get('relative_encoding', False)
+        self.rand_light = config.get('rand_light', [-1, 1, -0.2, 0.8, -0.1, 0.6, -0.6])
+        self.truncation = config.get('truncation', 1)
+        if self.truncation < 1:
+            with torch.no_grad():
+                self.mean_latent = self.generator.mean_latent(4096)
+        else:
+            self.mean_latent = None
+        self.renderer = Renderer(config, self.image_size, self.min_depth, self.max_depth,
+                                 device=self.device)
+
+        view_mvn_path = config.get('view_mvn_path', 'checkpoints/view_light/view_mvn.pth')
+        light_mvn_path = config.get('light_mvn_path', 'checkpoints/view_light/light_mvn.pth')
+        self.view_light_sampler = ViewLightSampler(view_mvn_path, light_mvn_path,
+                                                   config.get('view_scale', 1), self.device,
+                                                   config.get('view_mvn'), config.get('light_mvn'))
+        self.ckpt_paths = config.get('our_nets_ckpts')
+
+        # losses (model.py:77-83)
+        self.smooth_loss = SmoothLoss()
+        self.perceptual_loss = PerceptualLoss(
+            model='net-lin', net='vgg', lin_weights_path=config.get('lpips_lin_weights'),
+            vgg_weights_path=config.get('lpips_vgg_weights')).to(self.device)
+        self.discriminator_loss = DiscriminatorLoss()
+        self.photometric_loss = PhotometricLoss()
+
+        self._depth_border = None
+        self._centers = None
+
+    # ------------------------------------------------------------------ small helpers
+    def rescale_depth(self, depth):
+        return (1 + depth) / 2 * self.max_depth + (1 - depth) / 2 * self.min_depth
+
+    def depth_net_forward(self, inputs, prior):
+        """model.py:88-93, including the (B,H,W) - (1,1,1,1) broadcast to a 4-D depth."""
+        depth_raw = self.depth_net(inputs).squeeze(1)
+        depth = depth_raw - depth_raw.view(1, 1, -1).mean(2).view(1, 1, 1, 1)
+        depth = depth.tanh()
+        depth = self.rescale_depth(depth)
+        return F.mse_loss(depth[0], prior.detach().expand(depth.size(1), -1, -1)), depth
+
+    def get_view_transformation(self, view):
+        return torch.cat([view[:, :3] * math.pi / 180 * self.xyz_rotation_range,
+                          view[:, 3:5] * self.xy_translation_range,
+                          view[:, 5:] * self.z_translation_range], 1)
+
+    def get_clamped_depth(self, depth_raw, h, w, clamp_border=True):
+        """model.py:337-345: centre over the WHOLE batch, tanh, rescale; the two left/right border
+        columns blend towards border_depth with weight 1.02."""
+        depth_centered = depth_raw - depth_raw.view(1, -1).mean(1).view(1, 1, 1)
+        depth = self.rescale_depth(torch.tanh(depth_centered))
+        if clamp_border:
+            if self._depth_border is None or self._depth_border.shape[-2:] != (h, w):
+                border = torch.zeros(1, h, w - 4, device=depth.device)
+                self._depth_border = F.pad(border, (2, 2), mode='constant', value=1.02)
+            depth = depth * (1 - self._depth_border) + self._depth_border * self.border_depth
+        return depth
+
+    def get_lighting_directions(self, lighting):
+        lighting_a = lighting[:, :1] / 2 + 0.5  # ambience term
+        lighting_b = lighting[:, 1:2] / 2 + 0.5  # diffuse term
+        lighting_d = torch.cat([lighting[:, 2:], lighting.new_ones(lighting.size(0), 1)], 1)
+        lighting_d = lighting_d / ((lighting_d ** 2).sum(1, keepdim=True)) ** 0.5
+        return lighting_a, lighting_b, lighting_d
+
+    def get_shading(self, normal, lighting_a, lighting_b, lighting_d, albedo):
+        diffuse_shading = (normal * lighting_d.view(-1, 1, 1, 3)).sum(3).clamp(min=0).unsqueeze(1)
+        shading = lighting_a.view(-1, 1, 1, 1) + lighting_b.view(-1, 1, 1, 1) * diffuse_shading
+        texture = (albedo / 2 + 0.5) * shading * 2 - 1
+        return diffuse_shading, texture
+
+    def _no_grad_if(self, cond):
+        return torch.no_grad() if cond else torch.enable_grad()
+
+    # ------------------------------------------------------------------ step 1
+    def forward_step1(self, images, latents, collected, step1=True, eval=False, **kwargs):
+        """model.py:95-173: optimise the albedo net (step1=True) / everything (step1=False)."""
+        b = 1
+        h, w = self.image_size, self.image_size
+        with self._no_grad_if(step1):
+            depth_raw = self.depth_net(images)
+        depth = self.get_clamped_depth(depth_raw.squeeze(1), h, w)
+        with self._no_grad_if(step1):
+            view = self.viewpoint_net(images)
+        view = view + self.view_light_sampler.view_mean.unsqueeze(0)
+        self.renderer.set_transform_matrices(self.get_view_transformation(view))
+
+        albedo = self.albedo_net(images)
+        with self._no_grad_if(step1):
+            lighting = self.lighting_net(images)
+        lighting = lighting + self.view_light_sampler.light_mean.unsqueeze(0)
+        lighting_a, lighting_b, lighting_d = self.get_lighting_directions(lighting)
+
+        normal = self.renderer.get_normal_from_depth(depth)
+        diffuse_shading, texture = self.get_shading(normal, lighting_a, lighting_b, lighting_d, albedo)
+
+        recon_depth = self.renderer.warp_canon_depth(depth)
+        grid_2d_from_canon = self.renderer.get_inv_warped_2d_grid(recon_depth)
+        margin = (self.max_depth - self.min_depth) / 2
+        # invalid border pixels have been clamped at max_depth+margin
+        recon_im_mask = (recon_depth < self.max_depth + margin).float().unsqueeze(1).detach()
+        recon_im = F.grid_sample(texture, grid_2d_from_canon, mode='bilinear',
+                                 align_corners=True).clamp(min=-1, max=1)
+        if eval:
+            return recon_im, recon_depth
+
+        loss_l1_im = self.photometric_loss(recon_im[:b], images, mask=recon_im_mask[:b])
+        loss_perc_im = self.perceptual_loss(recon_im[:b] * recon_im_mask[:b],
+                                            images * recon_im_mask[:b])
+        loss_perc_im = torch.mean(loss_perc_im)
+        loss_smooth = self.smooth_loss(depth) + self.smooth_loss(diffuse_shading)
+        loss_total = loss_l1_im + self.lam_perc * loss_perc_im + self.lam_smooth * loss_smooth
+
+        canon_mask = None if len(images) == 1 else [None] * len(images)
+        return loss_total, (normal, lighting_a, lighting_b, albedo, depth, canon_mask)
+
+    # ------------------------------------------------------------------ step 2
+    def _latent_centers(self):
+        if self._centers is None:
+            with torch.no_grad():
+                zero = torch.zeros(1, self.z_dim, device=self.device)
+                self._centers = (self.generator.style_forward(zero),
+                                 self.generator.style_forward(zero, depth=8 - 2))
+        return self._centers
+
+    def forward_step2(self, image, latent, collected, n_proj_samples=8, **kwargs):
+        """model.py:175-223: optimise the offset encoder so that G reproduces the pseudo samples."""
+        F1_d = 2  # number of mapping network layers used to regularize the latent offset
+        *tensors, canon_mask = collected
+        normal, light_a, light_b, albedo, depth = [t.detach() for t in tensors]
+
+        with torch.no_grad():
+            pseudo_im, mask = self.sample_pseudo_imgs(n_proj_samples, normal, light_a, light_b,
+                                                      albedo, depth, canon_mask)
+            gan_im = None
+            if self.relative_encoding:
+                gan_im, _ = self.generator([latent], input_is_w=True,
+                                           truncation_latent=self.mean_latent,
+                                           truncation=self.truncation, randomize_noise=False)
+                gan_im = utils.resize(gan_im.clamp(min=-1, max=1), [self.image_size, self.image_size])
+            center_w, center_h = self._latent_centers()
+
+        latent_projection = self.latent_projection(pseudo_im, gan_im, latent, center_w, center_h, F1_d)
+        projected_image, offset = self.generator.invert(pseudo_im, latent_projection,
+                                                        self.truncation, self.mean_latent)
+        projected_image = utils.resize(projected_image, [self.image_size, self.image_size])
+        self.loss_l1 = self.photometric_loss(projected_image, pseudo_im, mask=mask)
+        self.loss_rec = self.discriminator_loss(self.discriminator, projected_image, pseudo_im,
+                                                mask=mask)
+        self.loss_latent_norm = torch.mean(offset ** 2)
+        loss_total = self.loss_l1 + self.loss_rec + self.lam_regular * self.loss_latent_norm
+        return loss_total, (projected_image.detach(), mask.detach())
+
+    def latent_projection(self, image, gan_im, latent, center_w, center_h, F1_d):
+        """model.py:282-289."""
+        offset = self.offset_encoder_net(image)
+        if self.relative_encoding:
+            offset = offset - self.offset_encoder_net(gan_im)
+        hidden = offset + center_h
+        offset = self.generator.style_forward(hidden, skip=8 - F1_d) - center_w
+        return offset, latent + offset
+
+    def sample_pseudo_imgs(self, n_images, normal, light_a, light_b, albedo, depth, canon_mask=None):
+        """model.py:291-328: random relighting (3 uniform draws) + n random views."""
+        h, w = self.image_size, self.image_size
+        dev = self.device
+        x_min, x_max, y_min, y_max, diffuse_min, diffuse_max, alpha = self.rand_light
+        rand_light_dxy = torch.empty(n_images, 2, device=dev)
+        rand_light_dxy[:, 0].uniform_(x_min, x_max)
+        rand_light_dxy[:, 1].uniform_(y_min, y_max)
+        rand_light_d = torch.cat([rand_light_dxy, torch.ones(n_images, 1, device=dev)], 1)
+        rand_light_d = rand_light_d / ((rand_light_d ** 2).sum(1, keepdim=True)) ** 0.5
+        rand_diffuse_shading = (normal[0, None] * rand_light_d.view(-1, 1, 1, 3)).sum(3)\
+            .clamp(min=0).unsqueeze(1)
+        rand = torch.empty(n_images, 1, 1, 1, device=dev).uniform_(diffuse_min, diffuse_max)
+        rand_diffuse = (light_b[0, None].view(-1, 1, 1, 1) + rand) * rand_diffuse_shading
+        rand_shading = light_a[0, None].view(-1, 1, 1, 1) + alpha * rand + rand_diffuse
+        rand_light_im = (albedo[0, None] / 2 + 0.5) * rand_shading * 2 - 1
+
+        depth = depth[0, None]
+        if canon_mask is not None:
+            mask = canon_mask.expand(n_images, 3, h, w)
+        else:
+            mask = torch.ones(n_images, 3, h, w, device=dev)
+
+        rand_views = self.view_light_sampler.sample(n_images, 'view')
+        rand_views_trans = self.get_view_transformation(rand_views)
+        pseudo_im, mask = self.renderer.render_given_view(rand_light_im, depth.expand(n_images, h, w),
+                                                          view=rand_views_trans, mask=mask,
+                                                          grid_sample=True)
+        mask = mask[:, 0, None, ...]
+        return pseudo_im.clamp(min=-1, max=1), mask.contiguous()
+
+    # ------------------------------------------------------------------ step 3
+    def forward_step3(self, images, latents, collected, **kwargs):
+        """model.py:225-280: optimise V, L, D, A on the image and its projected samples."""
+        projected_samples, masks = collected
+        # the reference draws (and discards) a permutation here (model.py:231-233): keep the draw so
+        # that a seeded run consumes the CPU generator identically
+        torch.randperm(len(projected_samples))
+        projected_samples, masks = projected_samples.to(self.device), masks.to(self.device)
+
+        step1_loss, collected = self.forward_step1(images, None, None, step1=False)
+        normal, _, _, albedo, depth, _ = collected
+
+        b = len(projected_samples)
+        view = self.viewpoint_net(projected_samples) + self.view_light_sampler.view_mean.unsqueeze(0)
+        self.renderer.set_transform_matrices(self.get_view_transformation(view))
+        light = self.lighting_net(projected_samples) + self.view_light_sampler.light_mean.unsqueeze(0)
+        light_a, light_b, light_d = self.get_lighting_directions(light)
+        diffuse_shading, texture = self.get_shading(normal, light_a, light_b, light_d, albedo)
+
+        depth = depth.expand(b, self.image_size, self.image_size)
+        recon_depth = self.renderer.warp_canon_depth(depth)
+        grid_2d_from_canon = self.renderer.get_inv_warped_2d_grid(recon_depth)
+        margin = (self.max_depth - self.min_depth) / 2
+        recon_im_mask = (recon_depth < self.max_depth + margin).float().unsqueeze(1).detach() * masks
+        recon_im = F.grid_sample(texture, grid_2d_from_canon, mode='bilinear',
+                                 align_corners=True).clamp(min=-1, max=1)
+
+        loss_l1_im = self.photometric_loss(recon_im[:b], projected_samples, mask=recon_im_mask[:b])
+        loss_perc_im = self.perceptual_loss(recon_im[:b] * recon_im_mask[:b],
+                                            projected_samples * recon_im_mask[:b])
+        loss_perc_im = torch.mean(loss_perc_im)
+        return step1_loss + loss_l1_im + self.lam_perc * loss_perc_im, None
+
+    # ------------------------------------------------------------------ evaluation / checkpoints
+    def evaluate_results(self, image):
+        """model.py:362-368."""
+        with torch.no_grad():
+            recon_im, recon_depth = self.forward_step1(image, None, None, eval=True)
+            depth_raw = self.depth_net(image).squeeze(1)
+            recon_depth = self.get_clamped_depth(depth_raw, self.image_size, self.image_size,
+                                                 clamp_border=False)
+        return recon_im, recon_depth
+
+    def reinitialize_model(self):
+        """model.py:370-383 (never called by the reference's trainer)."""
+        for name in GAN2Shape.NETS:
+            for layer in getattr(self, f'{name}_net').modules():
+                if hasattr(layer, 'reset_parameters'):
+                    layer.reset_parameters()
+
+    def save_checkpoint(self, img_idx, stage, total_it, category='car'):
+        """model.py:385-408: one .pth per net, {total_it, dataset, model_state_dict}."""
+        now = datetime.datetime.now().strftime("%Y_%m_%d_%H_%M")
+        for net in GAN2Shape.NETS:
+            save_dict = {'total_it': total_it, 'dataset': category,
+                         'model_state_dict': getattr(self, f'{net}_net').state_dict()}
+            filename = self.build_checkpoint_path(self.ckpt_paths['VLADE_nets'], category, net,
+                                                  img_idx, stage, total_it, now)
+            os.makedirs(os.path.dirname(filename), exist_ok=True)
+            with open(filename, 'wb') as f:
+                torch.save(save_dict, f)
+
+    def load_from_checkpoints(self, path_base, category):
+        paths, indices = self.build_checkpoint_path(path_base, category)
+        for path, img_idx in zip(paths, indices):
+            self.load_from_checkpoint(path)
+            yield img_idx
+
+    def load_from_checkpoint(self, filename_path):
+        """model.py:416-423: weights only (no optimiser state, no iteration resume)."""
+        for net in GAN2Shape.NETS:
+            with open(filename_path(net), 'rb') as f:
+                checkpoint = torch.load(f, map_location=self.device, weights_only=True)
+            getattr(self, f'{net}_net').load_state_dict(checkpoint['model_state_dict'])
+
+    def build_checkpoint_path(self, base, category, net=None, img_idx="*", stage="*",
+                              total_it="*", time="*", general=False):
+        """model.py:425-445."""
+        if net is not None:
+            return f'{base}/{category}/{net}_image_{img_idx}_stage_{stage}_{total_it}_it_{time}.pth'
+        net = GAN2Shape.NETS[0]
+        possible_paths = glob(f'{base}/{category}/{net}_image_*_stage_*_*_it_*.pth')
+        assert possible_paths
+        paths, img_ids = [], []
+        for path in sorted(possible_paths):
+            beginning, end = path.split(net)[:2]
+            paths.append(lambda x, b=beginning, e=end: f'{b}{x}{e}')
+            words = path.split('_')
+            if not general:
+                img_ids.append(int(words[words.index('image') + 1]))
+        return paths, img_ids
+
+
+class ViewLightSampler():
+    """model.py:448-470.  Samples one at a time (n sequential MultivariateNormal draws) so that a
+    seeded run consumes the device generator in the reference's order."""
+
+    def __init__(self, view_mvn_path, light_mvn_path, view_scale, device="cuda",
+                 view_mvn=None, light_mvn=None):
+        def load(path, fallback, dim):
+            if path and os.path.exists(path):
+                d = torch.load(path, map_location="cpu", weights_only=True)
+                return d['mean'].float(), d['cov'].float()
+            if fallback is not None:
+                return (torch.tensor(fallback['mean'], dtype=torch.float32),
+                        torch.tensor(fallback['cov'], dtype=torch.float32))
+            raise FileNotFoundError(f"{path} not found and no inline mean/cov given in the config")
+
+        vm, vc = load(view_mvn_path, view_mvn, 6)
+        lm, lc = load(light_mvn_path, light_mvn, 4)
+        self.view_mean = vm.to(device)
+        self.light_mean = lm.to(device)
+        self.view_scale = view_scale
+        self.view_dist = MultivariateNormal(vm.to(device), vc.to(device))
+        self.light_dist = MultivariateNormal(lm.to(device), lc.to(device))
+
+    def _sample(self, sample_type):
+        sample = getattr(self, f'{sample_type}_dist').sample()[None, :]
+        if sample_type == 'view':
+            sample[0, 1] *= self.view_scale
+        return sample
+
+    def sample(self, n=1, sample_type='view'):
+        return torch.cat([self._sample(sample_type) for _ in range(n)], dim=0)

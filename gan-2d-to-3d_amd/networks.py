@@ -1,0 +1,135 @@
+"""D / A / V / L / E networks of GAN2Shape (arxiv 2011.00844, tables 5-8), state-dict compatible
+with GAN2Shape/networks.py:23-244 (`network.<idx>.weight` keys).  Plain torch.nn on MIOpen — these
+nets are callers inside the step, not custom-kernel targets.
+
+PSPNet / BiSeNet / ResNet (networks.py:247-586) only feed the one-shot masking model and are out
+of scope.  The debug gradient alerts (debug_grad_updates.py) are dropped; `debug` is accepted and
+ignored.
+"""
+import torch.nn as nn
+
+
+class Encoder(nn.Module):
+    """ViewpointNet / LightingNet trunk (networks.py:23-50)."""
+
+    def __init__(self, cin, cout, size):
+        super().__init__()
+        nf = max(4096 // size, 16)
+        chans = [cin, nf, nf * 2, nf * 4, nf * 8, nf * 16]
+        layers = []
+        for a, b in zip(chans[:-1], chans[1:]):
+            layers += [nn.Conv2d(a, b, kernel_size=4, stride=2, padding=1, bias=False),
+                       nn.ReLU(inplace=True)]
+        layers += [nn.Conv2d(nf * 16, nf * 16, kernel_size=4, stride=1, padding=0, bias=False),
+                   nn.ReLU(inplace=True),
+                   nn.Conv2d(nf * 16, cout, kernel_size=1, stride=1, padding=0, bias=False),
+                   nn.Tanh()]
+        self.network = nn.Sequential(*layers)
+
+    def forward(self, input):
+        return self.network(input).reshape(input.size(0), -1)
+
+
+class ViewpointNet(Encoder):
+    def __init__(self, image_size, debug=False):
+        super().__init__(cin=3, cout=6, size=image_size)
+
+
+class LightingNet(Encoder):
+    def __init__(self, image_size, debug=False):
+        super().__init__(cin=3, cout=4, size=image_size)
+
+
+class EncoderDecoder(nn.Module):
+    """DepthNet / AlbedoNet trunk (networks.py:79-141)."""
+
+    def __init__(self, cin, cout, size, activation, zdim=256):
+        super().__init__()
+        nf = max(4096 // size, 16)
+        g = 8 if size >= 128 else 16
+
+        def down(a, b, groups):
+            layers = [nn.Conv2d(a, b, kernel_size=4, stride=2, padding=1, bias=False)]
+            if groups:
+                layers.append(nn.GroupNorm(groups, b))
+            return layers + [nn.LeakyReLU(0.2, inplace=True)]
+
+        def up(a, b, groups):
+            return [nn.ConvTranspose2d(a, b, kernel_size=4, stride=2, padding=1, bias=False),
+                    nn.GroupNorm(groups, b), nn.ReLU(inplace=True),
+                    nn.Conv2d(b, b, kernel_size=3, stride=1, padding=1, bias=False),
+                    nn.GroupNorm(groups, b), nn.ReLU(inplace=True)]
+
+        network = down(cin, nf, g) + down(nf, nf * 2, g * 2) + down(nf * 2, nf * 4, g * 4) + \
+            down(nf * 4, nf * 8, 0)
+        network += [nn.Conv2d(nf * 8, zdim, kernel_size=4, stride=1, padding=0, bias=False),
+                    nn.ReLU(inplace=True),
+                    nn.ConvTranspose2d(zdim, nf * 8, kernel_size=4, stride=1, padding=0, bias=False),
+                    nn.ReLU(inplace=True),
+                    nn.Conv2d(nf * 8, nf * 8, kernel_size=3, stride=1, padding=1, bias=False),
+                    nn.ReLU(inplace=True)]
+        network += up(nf * 8, nf * 4, g * 4) + up(nf * 4, nf * 2, g * 2) + up(nf * 2, nf, g)
+        network += [nn.Upsample(scale_factor=2, mode='nearest'),
+                    nn.Conv2d(nf, nf, kernel_size=3, stride=1, padding=1, bias=False),
+                    nn.GroupNorm(g, nf), nn.ReLU(inplace=True),
+                    nn.Conv2d(nf, nf, kernel_size=5, stride=1, padding=2, bias=False),
+                    nn.GroupNorm(g, nf), nn.ReLU(inplace=True),
+                    nn.Conv2d(nf, cout, kernel_size=5, stride=1, padding=2, bias=False)]
+        if activation is not None:
+            network += [activation()]
+        self.network = nn.Sequential(*network)
+
+    def forward(self, input):
+        return self.network(input)
+
+
+class DepthNet(EncoderDecoder):
+    def __init__(self, image_size, debug=False):
+        super().__init__(cin=3, cout=1, size=image_size, activation=None)
+
+
+class AlbedoNet(EncoderDecoder):
+    def __init__(self, image_size, debug=False):
+        super().__init__(cin=3, cout=3, size=image_size, activation=nn.Tanh)
+
+
+class ResBlock(nn.Module):
+    """Residual block of the offset encoder (networks.py:170-194)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.res_path = nn.Sequential(
+            nn.ReLU(), nn.Conv2d(cin, cout, kernel_size=3, stride=2, padding=1),
+            nn.ReLU(), nn.Conv2d(cout, cout, kernel_size=3, stride=1, padding=1))
+        self.identity_path = nn.Sequential(
+            nn.AvgPool2d(stride=2, kernel_size=2),
+            nn.Conv2d(cin, cout, kernel_size=1, stride=1, padding=0))
+
+    def forward(self, x):
+        return self.identity_path(x) + self.res_path(x)
+
+
+class OffsetEncoder(nn.Module):
+    """GAN latent-offset encoder E (networks.py:197-243).  image_size 64: the reference passes
+    `cout/2` (a float) to nn.Conv2d and cannot be constructed (networks.py:231); here the 64 branch
+    emits `cout` channels (documented deviation, plumbing config only)."""
+
+    def __init__(self, image_size=128, cin=3, cout=512, activation=None, debug=False):
+        super().__init__()
+        assert image_size in [64, 128]
+        nf = 16
+        network = [nn.Conv2d(cin, 2 * nf, kernel_size=4, stride=2, padding=1), nn.ReLU(),
+                   ResBlock(2 * nf, 4 * nf), ResBlock(4 * nf, 8 * nf), ResBlock(8 * nf, 16 * nf)]
+        if image_size == 128:
+            network += [ResBlock(16 * nf, 32 * nf),
+                        nn.Conv2d(32 * nf, 64 * nf, kernel_size=4, stride=1, padding=0), nn.ReLU(),
+                        nn.Conv2d(64 * nf, cout, kernel_size=1, stride=1, padding=0)]
+        else:
+            network += [nn.Conv2d(16 * nf, 32 * nf, kernel_size=4, stride=1, padding=0), nn.ReLU(),
+                        nn.Conv2d(32 * nf, cout, kernel_size=1, stride=1, padding=0)]
+        if activation is not None:
+            network += [activation()]
+        self.network = nn.Sequential(*network)
+
+    def forward(self, x):
+        return self.network(x).reshape(x.size(0), -1)

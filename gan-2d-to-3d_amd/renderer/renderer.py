@@ -1,0 +1,147 @@
+"""Mirror of the training-path methods of GAN2Shape/renderer/renderer.py:13-139,252-264.
+
+Same constructor and method names / argument meaning as the reference `Renderer`; the rasterizer
+behind `warp_canon_depth` is the libg2s kernel (through the neural_renderer drop-in).  Differences
+that do not change results: tensors are created on `device` directly (the reference hard-codes
+.cuda()); the pixel grid, face list and rotation centre are built once; `grid_sample` gets
+`align_corners=True` explicitly (the reference targets torch 1.2 where that was the only
+behaviour).  render_yaw / render_view / downscale_K and the
+grid_sample=False branch of render_given_view (render_rgb texture path) are out of scope.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..plugins import neural_renderer as nr
+from .utils import get_face_idx, get_grid, get_transform_matrices
+
+EPS = 1e-7
+
+
+class Renderer():
+    def __init__(self, cfgs, image_size, min_depth, max_depth, device="cuda"):
+        self.device = torch.device(device)
+        self.image_size = image_size
+        self.min_depth = min_depth
+        self.max_depth = max_depth
+        self.rot_center_depth = cfgs.get('rot_center_depth', (self.min_depth + self.max_depth) / 2)
+        self.fov = cfgs.get('fov', 10)
+        self.tex_cube_size = cfgs.get('tex_cube_size', 2)
+        self.renderer_min_depth = cfgs.get('renderer_min_depth', 0.1)
+        self.renderer_max_depth = cfgs.get('renderer_max_depth', 10.)
+
+        # pinhole intrinsics (renderer.py:35-46):  d * K^-1 (u, v, 1)^T = (x, y, z)^T
+        R = torch.eye(3, device=self.device).unsqueeze(0)
+        t = torch.zeros(1, 3, dtype=torch.float32, device=self.device)
+        fx = (self.image_size - 1) / 2 / (math.tan(self.fov / 2 * math.pi / 180))
+        fy = (self.image_size - 1) / 2 / (math.tan(self.fov / 2 * math.pi / 180))
+        cx = (self.image_size - 1) / 2
+        cy = (self.image_size - 1) / 2
+        K = torch.tensor([[fx, 0., cx], [0., fy, cy], [0., 0., 1.]], dtype=torch.float32,
+                         device=self.device)
+        self.inv_K_origin = torch.inverse(K).unsqueeze(0)
+        self.K_origin = K.unsqueeze(0)
+        self.inv_K = self.inv_K_origin.clone()
+        self.K = self.K_origin.clone()
+        self.renderer = nr.Renderer(camera_mode='projection',
+                                    light_intensity_ambient=1.0,
+                                    light_intensity_directional=0.,
+                                    K=self.K, R=R, t=t,
+                                    near=self.renderer_min_depth, far=self.renderer_max_depth,
+                                    image_size=self.image_size, orig_size=self.image_size,
+                                    fill_back=True,
+                                    background_color=[1, 1, 1])
+        self._centroid = torch.tensor([0., 0., self.rot_center_depth], device=self.device).view(1, 1, 3)
+        self._rays = {}
+
+    def set_transform_matrices(self, view):
+        self.rot_mat, self.trans_xyz = get_transform_matrices(view)
+
+    def rotate_pts(self, pts, rot_mat):
+        centroid = self._centroid.to(pts.device)
+        pts = pts - centroid          # move to centroid
+        pts = pts.matmul(rot_mat.transpose(2, 1))  # rotate
+        return pts + centroid         # move back
+
+    def translate_pts(self, pts, trans_xyz):
+        return pts + trans_xyz
+
+    def _pixel_rays(self, h, w, device):
+        """K^-1 (u, v, 1)^T for every pixel, (1, h, w, 3): constant, built once."""
+        key = (h, w, str(device))
+        r = self._rays.get(key)
+        if r is None:
+            grid_2d = get_grid(1, h, w, normalize=False, device=device)
+            grid_3d = torch.cat((grid_2d, torch.ones(1, h, w, 1, device=device)), dim=3)
+            r = grid_3d.matmul(self.inv_K.to(device).transpose(2, 1))
+            self._rays[key] = r
+        return r
+
+    def depth_to_3d_grid(self, depth):
+        b, h, w = depth.shape
+        return self._pixel_rays(h, w, depth.device) * depth.unsqueeze(-1)
+
+    def grid_3d_to_2d(self, grid_3d):
+        b, h, w, _ = grid_3d.shape
+        grid_2d = grid_3d / grid_3d[..., 2:]
+        grid_2d = grid_2d.matmul(self.K.to(grid_3d.device).transpose(2, 1))[:, :, :, :2]
+        WH = torch.tensor([w - 1, h - 1], dtype=torch.float32, device=grid_3d.device).view(1, 1, 1, 2)
+        return grid_2d / WH * 2. - 1.  # normalize to -1~1
+
+    def get_warped_3d_grid(self, depth):
+        b, h, w = depth.shape
+        grid_3d = self.depth_to_3d_grid(depth).reshape(b, -1, 3)
+        grid_3d = self.rotate_pts(grid_3d, self.rot_mat)
+        grid_3d = self.translate_pts(grid_3d, self.trans_xyz)
+        return grid_3d.reshape(b, h, w, 3)
+
+    def get_inv_warped_3d_grid(self, depth):
+        b, h, w = depth.shape
+        grid_3d = self.depth_to_3d_grid(depth).reshape(b, -1, 3)
+        grid_3d = self.translate_pts(grid_3d, -self.trans_xyz)
+        grid_3d = self.rotate_pts(grid_3d, self.rot_mat.transpose(2, 1))
+        return grid_3d.reshape(b, h, w, 3)
+
+    def get_warped_2d_grid(self, depth):
+        return self.grid_3d_to_2d(self.get_warped_3d_grid(depth))
+
+    def get_inv_warped_2d_grid(self, depth):
+        return self.grid_3d_to_2d(self.get_inv_warped_3d_grid(depth))
+
+    def warp_canon_depth(self, canon_depth):
+        b, h, w = canon_depth.shape
+        grid_3d = self.get_warped_3d_grid(canon_depth).reshape(b, -1, 3)
+        faces = get_face_idx(b, h, w, device=canon_depth.device)
+        warped_depth = self.renderer.render_depth(grid_3d, faces)
+        # allow some margin out of valid range
+        margin = (self.max_depth - self.min_depth) / 2
+        return warped_depth.clamp(min=self.min_depth - margin, max=self.max_depth + margin)
+
+    def get_normal_from_depth(self, depth):
+        b, h, w = depth.shape
+        grid_3d = self.depth_to_3d_grid(depth)
+        tu = grid_3d[:, 1:-1, 2:] - grid_3d[:, 1:-1, :-2]
+        tv = grid_3d[:, 2:, 1:-1] - grid_3d[:, :-2, 1:-1]
+        normal = torch.linalg.cross(tu, tv, dim=3)
+        # border pixels get (0, 0, 1)
+        normal = nn.functional.pad(normal.permute(0, 3, 1, 2), (1, 1, 1, 1)).permute(0, 2, 3, 1)
+        border = torch.ones(1, h, w, 1, device=depth.device)
+        border[:, 1:-1, 1:-1] = 0
+        normal = normal + border * torch.tensor([0., 0., 1.], device=depth.device)
+        return normal / (((normal ** 2).sum(3, keepdim=True)) ** 0.5 + EPS)
+
+    def render_given_view(self, im, depth, view, mask=None, grid_sample=True):
+        if not grid_sample:
+            raise NotImplementedError("render_given_view(grid_sample=False) uses render_rgb "
+                                      "(texture path): outside the training hot path")
+        self.set_transform_matrices(view)
+        recon_depth = self.warp_canon_depth(depth)
+        grid_2d_from_canon = self.get_inv_warped_2d_grid(recon_depth)
+        warped_images = nn.functional.grid_sample(im, grid_2d_from_canon, mode='bilinear',
+                                                  align_corners=True)
+        if mask is not None:
+            warped_mask = nn.functional.grid_sample(mask, grid_2d_from_canon, mode='nearest',
+                                                    align_corners=True)
+            return warped_images, warped_mask
+        return warped_images

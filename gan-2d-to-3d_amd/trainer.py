@@ -1,0 +1,118 @@
+"""Instance-wise training loop: mirror of GAN2Shape/trainer.py:13-171 (`Trainer`).
+
+Same constructor and `fit` signature, so `Trainer(model=GAN2Shape, model_config=cfg, ...)` works as
+in the reference's main.py:130-153: per image, optional prior pre-training of the depth net, then
+stages x steps {1,2,3} x N iterations of zero_grad / forward_stepK / backward / Adam.step, with the
+last `collected` of step K handed to step K+1.  Three persistent Adam optimisers over {A}, {E},
+{L,V,D,A} (lr 1e-4, classic L2 weight decay 5e-4), a fresh Adam for every image's prior
+pre-training (trainer.py:40-48,131,163-171).
+
+Added (not in the reference): `rank` / `world_size` image sharding — rank r trains images
+r, r+W, r+2W, ... with no collective (the per-image optimisation is independent; note that nets
+are carried from image to image, so a shard equals the reference run on that rank's subset).
+Plotting / wandb hooks are out of scope.
+"""
+import logging
+
+import torch
+from torch.utils.data import DataLoader, Subset
+
+from .priors import PriorGenerator
+
+
+def shard_indices(n_items, rank, world_size):
+    """Images of rank `rank`: rank, rank + W, rank + 2W, ..."""
+    return list(range(rank, n_items, world_size))
+
+
+class Trainer():
+    def __init__(self, model, model_config, debug=False, plot_intermediate=False, log_wandb=False,
+                 save_ckpts=False, load_dict=None, masking_model=None, device="cuda"):
+        try:
+            self.model = model(model_config, debug, device=device)
+        except TypeError:  # a model class with the reference's exact (config, debug) signature
+            self.model = model(model_config, debug)
+        self.device = torch.device(device)
+        self.image_size = model_config.get('image_size')
+        self.category = model_config.get('category')
+        self.n_proj_samples = model_config.get('n_proj_samples', 8)
+        self.n_epochs_prior = model_config.get('n_epochs_prior', 1000)
+        self.n_workers = model_config.get('n_workers', 0)
+        self.learning_rate = model_config.get('learning_rate', 1e-4)
+        self.save_ckpts = save_ckpts
+        self.debug = debug
+        self.prior_generator = PriorGenerator(self.image_size, self.category,
+                                              model_config.get('prior_name', 'ellipsoid'),
+                                              masking_model=masking_model)
+        self.optim_step1 = Trainer.default_optimizer([self.model.albedo_net], lr=self.learning_rate)
+        self.optim_step2 = Trainer.default_optimizer([self.model.offset_encoder_net],
+                                                     lr=self.learning_rate)
+        self.optim_step3 = Trainer.default_optimizer([self.model.lighting_net,
+                                                      self.model.viewpoint_net,
+                                                      self.model.depth_net,
+                                                      self.model.albedo_net], lr=self.learning_rate)
+        self.load_dict = load_dict
+        if load_dict is not None:
+            paths, _ = self.model.build_checkpoint_path(load_dict['base_path'],
+                                                        load_dict['category'], general=True)
+            self.model.load_from_checkpoint(paths[-1])
+        self.history = []  # (image index, stage, step, last loss) per finished step block
+
+    def fit(self, images_latents, plot_depth_map=False,
+            stages=[{'step1': 1, 'step2': 1, 'step3': 1}] * 2, shuffle=False,
+            rank=0, world_size=1, **_):
+        total_it = 0
+        n_stages = len(stages)
+        data = images_latents
+        if world_size > 1:
+            data = Subset(images_latents, shard_indices(len(images_latents), rank, world_size))
+        # the original training is instance-based => batch size = 1
+        dataloader = DataLoader(data, batch_size=1, shuffle=shuffle, num_workers=self.n_workers)
+        for batch in dataloader:
+            image, latent, data_index = batch
+            image, latent = image.to(self.device), latent.to(self.device)
+            data_index = int(data_index[0])
+            logging.info(f'Training on image {data_index}')
+            if not self.debug and self.load_dict is None:
+                self.pretrain_on_prior(image, data_index, plot_depth_map)
+            stage = 0
+            for stage in range(n_stages):
+                old_collected = None
+                for step in [1, 2, 3]:
+                    optim = getattr(self, f'optim_step{step}')
+                    forward = getattr(self.model, f'forward_step{step}')
+                    collected, loss = None, None
+                    for _ in range(stages[stage][f'step{step}']):
+                        optim.zero_grad()
+                        loss, collected = forward(image, latent, old_collected,
+                                                  n_proj_samples=self.n_proj_samples)
+                        loss.backward()
+                        optim.step()
+                        total_it += 1
+                    self.history.append((data_index, stage, step,
+                                         None if loss is None else float(loss.detach())))
+                    old_collected = collected
+            if self.save_ckpts:
+                self.model.save_checkpoint(data_index, stage, total_it, self.category)
+        logging.info('Finished Training')
+        return total_it
+
+    def pretrain_on_prior(self, image, i_batch, plot_depth_map=False):
+        """trainer.py:130-161: n_epochs_prior Adam steps of mse(depth, prior) on a fresh optimiser."""
+        optim = Trainer.default_optimizer([self.model.depth_net])
+        prior = self.prior_generator(image, device=self.device)
+        losses = []
+        for _ in range(self.n_epochs_prior):
+            optim.zero_grad()
+            loss, depth = self.model.depth_net_forward(image, prior)
+            loss.backward()
+            optim.step()
+            losses.append(loss.detach())
+        return [float(v) for v in torch.stack(losses).cpu()] if losses else []
+
+    @staticmethod
+    def default_optimizer(model_list, lr=1e-4, betas=(0.9, 0.999), weight_decay=5e-4):
+        param_list = []
+        for model in model_list:
+            param_list += [p for p in model.parameters() if p.requires_grad]
+        return torch.optim.Adam(param_list, lr=lr, betas=betas, weight_decay=weight_decay)

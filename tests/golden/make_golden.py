@@ -187,10 +187,65 @@ def misc_golden():
     np.savez_compressed(os.path.join(OUT, "misc.npz"), **out)
 
 
+def fill_deterministic(module, seed):
+    """Overwrite every parameter and buffer with seeded values, visiting the state dict in sorted
+    key order — the test does the same on the build's state-dict-compatible module, so the weights
+    need not be stored."""
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k in sorted(sd.keys()):
+            t = sd[k]
+            if not t.is_floating_point():
+                continue
+            if k.endswith("kernel"):
+                continue  # FIR taps stay as constructed
+            v = torch.randn(t.shape, generator=g)
+            if "modulation.bias" in k:
+                v = 1 + 0.1 * v
+            elif k.endswith("bias") or "noise" in k:
+                v = 0.1 * v
+            t.copy_(v)
+
+
+def gan_golden():
+    sys.path.insert(0, SG2)
+    import model as sg2
+    out = {}
+    g = sg2.Generator(16, 32, 3, channel_multiplier=1)
+    fill_deterministic(g, 123)
+    g.eval()
+    torch.manual_seed(0)
+    w = torch.randn(2, 32, requires_grad=True)
+    img, _ = g([w], input_is_w=True, randomize_noise=False)
+    gy = torch.randn_like(img)
+    (gw,) = torch.autograd.grad(img, w, gy)
+    out["g.w"], out["g.img"], out["g.gy"], out["g.gw"] = np_(w), np_(img), np_(gy), np_(gw)
+    z = torch.randn(2, 32)
+    img2, _ = g([z], input_is_w=False, randomize_noise=False)
+    out["g.z"], out["g.img_from_z"] = np_(z), np_(img2)
+    out["g.n_keys"] = np.array(len(g.state_dict()))
+
+    d = sg2.Discriminator(16, channel_multiplier=1)
+    fill_deterministic(d, 321)
+    d.eval()
+    x = torch.randn(2, 3, 16, 16, requires_grad=True)
+    _, feats = d(x, ftr_num=2)
+    gf = [torch.randn_like(f) for f in feats]
+    (gx,) = torch.autograd.grad(feats, x, gf)
+    out["d.x"], out["d.gx"] = np_(x), np_(gx)
+    for i, (f, g_) in enumerate(zip(feats, gf)):
+        out[f"d.f{i}"], out[f"d.gf{i}"] = np_(f), np_(g_)
+    score, feats_all = d(x)
+    out["d.score"] = np_(score)
+    np.savez_compressed(os.path.join(OUT, "gan.npz"), **out)
+
+
 if __name__ == "__main__":
     ops_golden()
     geometry_golden()
     misc_golden()
+    gan_golden()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,216 @@
+"""-m gpu: the StyleGAN2 host mirror and the GAN2Shape steps on the HIP kernels.
+
+Generator / Discriminator / mapping network are compared with outputs of the reference's own
+modules (tests/golden/gan.npz, mapping.npz: weights are regenerated from a seed in sorted
+state-dict order, exactly as tests/golden/make_golden.py filled the reference modules).
+warp_canon_depth is checked at the BASELINE size (S = 128) against the brute-force oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import capi  # noqa: E402
+from oracle import geometry as og  # noqa: E402
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def fill_deterministic(module, seed):
+    """Same recipe as tests/golden/make_golden.py:fill_deterministic."""
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k in sorted(sd.keys()):
+            t = sd[k]
+            if not t.is_floating_point() or k.endswith("kernel"):
+                continue
+            v = torch.randn(t.shape, generator=g)
+            if "modulation.bias" in k:
+                v = 1 + 0.1 * v
+            elif k.endswith("bias") or "noise" in k:
+                v = 0.1 * v
+            t.copy_(v)
+
+
+@pytest.fixture(scope="module")
+def sg2():
+    import gan2shape_amd  # noqa: F401
+    from gan2shape_amd import lib, stylegan2
+    lib.load()
+    return stylegan2
+
+
+def test_mapping_network_golden(sg2, golden):
+    g = golden("mapping")
+    G = sg2.Generator(8, 32, 4, channel_multiplier=1)
+    with torch.no_grad():
+        for i in range(1, 5):
+            G.style[i].weight.copy_(torch.tensor(g[f"style.{i}.weight"]))
+            G.style[i].bias.copy_(torch.tensor(g[f"style.{i}.bias"]))
+    G = G.cuda()
+    z = dev(g["style.z"])
+    np.testing.assert_allclose(G.style_forward(z).cpu().numpy(), g["style.full"], rtol=1e-5, atol=1e-6)
+    d3 = G.style_forward(z, depth=3)
+    np.testing.assert_allclose(d3.cpu().numpy(), g["style.depth3"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(G.style_forward(d3, skip=3).cpu().numpy(), g["style.skip3"], rtol=1e-5, atol=1e-6)
+
+
+def test_generator_golden(sg2, golden):
+    g = golden("gan")
+    G = sg2.Generator(16, 32, 3, channel_multiplier=1)
+    assert len(G.state_dict()) == int(g["g.n_keys"])
+    fill_deterministic(G, 123)
+    G = G.cuda().eval()
+    w = dev(g["g.w"]).requires_grad_(True)
+    img, _ = G([w], input_is_w=True, randomize_noise=False)
+    (gw,) = torch.autograd.grad(img, w, dev(g["g.gy"]))
+    scale = np.abs(g["g.img"]).max()
+    np.testing.assert_allclose(img.detach().cpu().numpy(), g["g.img"], atol=1e-4 * scale, rtol=1e-4)
+    np.testing.assert_allclose(gw.cpu().numpy(), g["g.gw"], atol=2e-4 * np.abs(g["g.gw"]).max(), rtol=1e-3)
+    with torch.no_grad():
+        img2, _ = G([dev(g["g.z"])], input_is_w=False, randomize_noise=False)
+    np.testing.assert_allclose(img2.cpu().numpy(), g["g.img_from_z"], atol=1e-4 * scale, rtol=1e-4)
+    # the frozen-generator path (requires_grad False: fused noise+bias+act) gives the same image
+    G.requires_grad_(False)
+    img3, _ = G([w], input_is_w=True, randomize_noise=False)
+    torch.testing.assert_close(img3, img, rtol=1e-5, atol=1e-5 * scale)
+    (gw3,) = torch.autograd.grad(img3, w, dev(g["g.gy"]))
+    torch.testing.assert_close(gw3, gw, rtol=1e-4, atol=1e-4 * float(gw.abs().max()))
+
+
+def test_discriminator_golden(sg2, golden):
+    g = golden("gan")
+    D = sg2.Discriminator(16, channel_multiplier=1)
+    fill_deterministic(D, 321)
+    D = D.cuda().eval()
+    x = dev(g["d.x"]).requires_grad_(True)
+    _, feats = D(x, ftr_num=2)
+    assert len(feats) == 2
+    (gx,) = torch.autograd.grad(feats, x, [dev(g["d.gf0"]), dev(g["d.gf1"])])
+    for i, f in enumerate(feats):
+        ref = g[f"d.f{i}"]
+        np.testing.assert_allclose(f.detach().cpu().numpy(), ref, atol=2e-4 * np.abs(ref).max(), rtol=1e-3)
+    np.testing.assert_allclose(gx.cpu().numpy(), g["d.gx"], atol=3e-4 * np.abs(g["d.gx"]).max(), rtol=1e-3)
+    score, _ = D(x)
+    np.testing.assert_allclose(score.detach().cpu().numpy(), g["d.score"],
+                               atol=3e-4 * np.abs(g["d.score"]).max(), rtol=1e-3)
+
+
+@pytest.fixture(scope="module")
+def trainer():
+    import bench
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import Trainer
+    torch.manual_seed(0)
+    t = Trainer(GAN2Shape, bench.face_config(n_proj=3), device="cuda")
+    t.sample = bench.synthetic_sample(t.model, 1234, torch.device("cuda"))
+    return t
+
+
+def _grad_norms(model):
+    out = {}
+    for name in model.NETS:
+        ps = [p.grad for p in getattr(model, f"{name}_net").parameters() if p.grad is not None]
+        out[name] = float(sum((g.double() ** 2).sum() for g in ps)) if ps else 0.0
+    return out
+
+
+def _zero(model):
+    for p in model.parameters():
+        p.grad = None
+
+
+def test_warp_canon_depth_full_size_vs_oracle(trainer):
+    """renderer.py:116-125 at S = 128 against the brute-force oracle (bit-exact depth)."""
+    m = trainer.model
+    S = 128
+    torch.manual_seed(1)
+    base = torch.tensor(og.Geometry(S).get_normal_from_depth(np.ones((1, S, S), np.float32))[..., 2])
+    depth = (1.0 + 0.06 * torch.sin(torch.arange(S).float()[None, :, None] / 7)
+             * torch.cos(torch.arange(S).float()[None, None, :] / 11) * base).cuda()
+    view = torch.tensor([[0.35, -0.6, 0.1, 0.03, -0.02, 0.05]], device="cuda")
+    m.renderer.set_transform_matrices(view)
+    with torch.no_grad():
+        out = m.renderer.warp_canon_depth(depth)
+        verts = m.renderer.get_warped_3d_grid(depth).reshape(1, -1, 3)
+    faces = og.get_face_idx(1, S, S)[0]
+    ref = capi.render_depth(verts.cpu().numpy(), faces, S, m.renderer.K[0].cpu().numpy())
+    np.testing.assert_array_equal(out.cpu().numpy(), np.clip(ref["depth"], 0.8, 1.2).astype(np.float32))
+    assert (out < 1.2).float().mean() > 0.5
+
+
+def test_three_steps_train_the_right_networks(trainer):
+    m = trainer.model
+    image, latent = trainer.sample
+    _zero(m)
+    loss1, col1 = m.forward_step1(image, latent, None)
+    assert torch.isfinite(loss1) and len(col1) == 6 and col1[4].shape == (1, 128, 128)
+    loss1.backward()
+    n = _grad_norms(m)
+    assert n["albedo"] > 0 and n["depth"] == n["viewpoint"] == n["lighting"] == n["offset_encoder"] == 0
+    assert all(p.grad is None for p in m.generator.parameters())
+
+    _zero(m)
+    loss2, col2 = m.forward_step2(image, latent, col1, n_proj_samples=3)
+    assert torch.isfinite(loss2)
+    proj, mask = col2
+    assert proj.shape == (3, 3, 128, 128) and mask.shape == (3, 1, 128, 128) and proj.is_cuda
+    loss2.backward()
+    n = _grad_norms(m)
+    assert n["offset_encoder"] > 0 and n["albedo"] == n["depth"] == n["viewpoint"] == n["lighting"] == 0
+
+    _zero(m)
+    loss3, col3 = m.forward_step3(image, latent, col2)
+    assert torch.isfinite(loss3) and col3 is None
+    loss3.backward()
+    n = _grad_norms(m)
+    assert n["depth"] > 0 and n["viewpoint"] > 0 and n["lighting"] > 0 and n["albedo"] > 0
+    assert n["offset_encoder"] == 0
+    rim, rdepth = m.evaluate_results(image)
+    assert rim.shape == (1, 3, 128, 128) and rdepth.shape == (1, 128, 128)
+
+
+def test_step2_is_reproducible_under_a_seed(trainer):
+    m = trainer.model
+    image, latent = trainer.sample
+    with torch.no_grad():
+        _, col1 = m.forward_step1(image, latent, None)
+    vals = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        loss, _ = m.forward_step2(image, latent, col1, n_proj_samples=3)
+        vals.append(loss.item())
+    assert vals[0] == vals[1]
+
+
+def test_trainer_fit_and_checkpoint_roundtrip(trainer, tmp_path):
+    from gan2shape_amd.model import GAN2Shape
+    image, latent = trainer.sample
+    data = [(image[0].cpu(), latent[0].cpu(), 0), (image[0].cpu().flip(2), latent[0].cpu(), 1)]
+    trainer.n_epochs_prior = 2
+    trainer.history.clear()
+    n = trainer.fit(data, stages=[{'step1': 1, 'step2': 1, 'step3': 1}])
+    assert n == 6 and len(trainer.history) == 6
+    assert all(math.isfinite(h[3]) for h in trainer.history)
+    # rank 1 of 2 sees only image 1
+    trainer.history.clear()
+    trainer.fit(data, stages=[{'step1': 1, 'step2': 0, 'step3': 0}], rank=1, world_size=2)
+    assert {h[0] for h in trainer.history} == {1}
+    m = trainer.model
+    m.ckpt_paths = {'VLADE_nets': str(tmp_path)}
+    m.save_checkpoint(0, 0, 6, 'face')
+    paths, ids = m.build_checkpoint_path(str(tmp_path), 'face')
+    assert ids == [0]
+    before = {k: v.clone() for k, v in m.depth_net.state_dict().items()}
+    with torch.no_grad():
+        for p in m.depth_net.parameters():
+            p.add_(1.0)
+    m.load_from_checkpoint(paths[0])
+    for k, v in m.depth_net.state_dict().items():
+        torch.testing.assert_close(v, before[k])
+    assert set(GAN2Shape.NETS) == {'lighting', 'viewpoint', 'depth', 'albedo', 'offset_encoder'}

@@ -1,0 +1,215 @@
+"""-m "not gpu": host logic that needs no kernel — the geometry mirror against the golden vectors,
+losses, resize, priors, state-dict compatibility with the reference modules (live, in the build
+container only), the C-ABI surface, sharding helpers."""
+import math
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import gan2shape_amd  # noqa: F401
+from gan2shape_amd import lib, losses, networks, priors, utils
+from gan2shape_amd.renderer import Renderer
+from gan2shape_amd.renderer import utils as ru
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+SG2 = os.path.join(REF, "GAN2Shape/stylegan2/stylegan2-pytorch")
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+
+
+def T(a):
+    return torch.as_tensor(a)
+
+
+# ----------------------------------------------------------------------------- C ABI
+def test_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "g2s.h")).read()
+    declared = set(re.findall(r"\b(g2s_[a-z0-9_]+)\s*\(", header))
+    assert {"g2s_raster_depth_fwd", "g2s_raster_depth_bwd", "g2s_fused_bias_act", "g2s_upfirdn2d",
+            "g2s_modconv", "g2s_noise_bias_act", "g2s_raster_workspace_bytes", "g2s_last_error",
+            "g2s_abi_version"} <= declared
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    L = lib.load()  # loads without a GPU; getattr fails for a missing symbol
+    assert L.g2s_abi_version() == 1
+    assert L.g2s_raster_workspace_bytes(8, 128 * 128, 2 * 127 * 127, 128) >= 8 * (16384 + 256) * 16
+    assert L.g2s_raster_workspace_bytes(0, 1, 1, 1) == 0
+
+
+def test_argument_validation_without_gpu():
+    """Validation happens before any launch, so it can be exercised on the CPU box."""
+    L = lib.load()
+    rc = L.g2s_fused_bias_act(None, None, None, None, 16, 1, 1, 3, 0, 0.2, 1.0, 0, None)
+    assert rc == -1 and b"NULL" in L.g2s_last_error()
+    rc = L.g2s_upfirdn2d(None, None, None, 1, 4, 4, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, 0, None)
+    assert rc == -1
+    rc = L.g2s_modconv(None, None, None, None, None, 1, 1, 1, 4, 4, 3, 0, 0, None)
+    assert rc == -1
+    K = (lib.C.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+    rc = L.g2s_raster_depth_fwd(None, None, 1, 16, 18, 4, K, 4.0, 2, 1, 0.1, 100.0, None, None, None,
+                                None, 0, None)
+    assert rc == -1
+    with pytest.raises(lib.G2SError):
+        lib.check(rc)
+
+
+def test_no_cpu_fallback():
+    from gan2shape_amd.op import fused_leaky_relu, upfirdn2d
+    with pytest.raises(RuntimeError):
+        fused_leaky_relu(torch.randn(2, 3), torch.zeros(3))
+    with pytest.raises(RuntimeError):
+        upfirdn2d(torch.randn(1, 1, 4, 4), torch.ones(4, 4))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gan-2d-to-3d_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                for pat in ("import oracle", "from oracle", "libg2s_oracle", "oracle.capi", "#include \"../../oracle"):
+                    assert pat not in src, (f, pat)
+
+
+# ----------------------------------------------------------------------------- geometry mirror
+def test_renderer_utils_golden(golden):
+    g = golden("geometry")
+    np.testing.assert_array_equal(ru.get_face_idx(2, 4, 4).numpy(), g["face_idx_4x4"])
+    np.testing.assert_array_equal(ru.get_face_idx(1, 3, 5).numpy(), g["face_idx_3x5"])
+    assert ru.get_face_idx(1, 4, 4).dtype == torch.int32
+    np.testing.assert_allclose(ru.get_grid(2, 3, 4, True).numpy(), g["grid_norm"], atol=1e-7)
+    np.testing.assert_array_equal(ru.get_grid(1, 3, 4, False).numpy(), g["grid_px"])
+    for n in (3, 5, 6):
+        r, t = ru.get_transform_matrices(T(g["view6"][:, :n]))
+        np.testing.assert_allclose(r.numpy(), g[f"rot{n}"], atol=1e-6)
+        np.testing.assert_array_equal(t.numpy(), g[f"trans{n}"])
+    with pytest.raises(Exception):
+        ru.get_transform_matrices(torch.zeros(1, 4))
+
+
+def test_renderer_geometry_golden(golden):
+    g = golden("geometry")
+    S = g["r.depth"].shape[1]
+    R = Renderer({"rot_center_depth": 1.0, "fov": 10}, S, 0.9, 1.1, device="cpu")
+    np.testing.assert_allclose(R.K.numpy(), g["r.K"], rtol=1e-6)
+    np.testing.assert_allclose(R.inv_K.numpy(), g["r.inv_K"], rtol=1e-5, atol=1e-7)
+    R.set_transform_matrices(T(g["r.view"]))
+    d = T(g["r.depth"])
+    np.testing.assert_allclose(R.depth_to_3d_grid(d).numpy(), g["r.grid3d"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(R.get_warped_3d_grid(d).numpy(), g["r.warped3d"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(R.get_inv_warped_3d_grid(d).numpy(), g["r.invwarped3d"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(R.get_inv_warped_2d_grid(d).numpy(), g["r.invwarped2d"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(R.get_normal_from_depth(d).numpy(), g["r.normal"], rtol=1e-4, atol=1e-5)
+
+
+def test_resize_golden(golden):
+    g = golden("misc")
+    x = T(g["resize.x"])
+    np.testing.assert_allclose(utils.resize(x, [16, 16]).numpy(), g["resize.up"], atol=1e-6)
+    np.testing.assert_allclose(utils.resize(x, [4, 4]).numpy(), g["resize.down"], atol=1e-6)
+    assert utils.resize(x, [8, 8]) is x
+    np.testing.assert_allclose(utils.resize(T(g["resize.x3"]), [4, 4]).numpy(), g["resize.down3"], atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- losses / priors
+def test_losses_closed_form():
+    a = torch.tensor([[[[1., 2.], [3., 4.]]]])
+    b = torch.zeros_like(a)
+    m = torch.tensor([[[[1., 0.], [0., 1.]]]])
+    assert losses.PhotometricLoss()(a, b).item() == 2.5
+    assert losses.PhotometricLoss()(a, b, mask=m).item() == 2.5
+    assert losses.PhotometricLoss()(a, b, mask=torch.tensor([[[[1., 0.], [0., 0.]]]])).item() == 1.0
+    # second differences of a quadratic ramp: d2/dx2 (x^2) = 2, everything else 0
+    x = torch.arange(6.).view(1, 1, 1, 6).expand(1, 1, 6, 6) ** 2
+    assert abs(losses.SmoothLoss()(x).item() - 2.0) < 1e-6
+    assert losses.SmoothLoss()(x[0]).item() == losses.SmoothLoss()([x]).item()
+
+    class FakeD:
+        def __call__(self, img, ftr_num):
+            return 0, [img * 2, img[:, :, ::2, ::2]][:ftr_num]
+    fake, real = torch.ones(1, 1, 4, 4), torch.zeros(1, 1, 4, 4)
+    mask = torch.ones(1, 1, 4, 4)
+    mask[..., 2:] = 0
+    dl = losses.DiscriminatorLoss(ftr_num=2)
+    assert abs(dl(FakeD(), fake, real).item() - 3.0) < 1e-6
+    assert abs(dl(FakeD(), fake, real, mask=mask).item() - 3.0) < 1e-6
+
+
+def test_priors_from_synthetic_mask():
+    img = torch.zeros(1, 3, 64, 64)
+    for name in ["ellipsoid", "smoothed_box", "masked_box", "box", "confidence", "smoothed_confidence"]:
+        p = priors.PriorGenerator(64, "face", name)(img, device="cpu")
+        assert p.shape == (1, 64, 64) and torch.isfinite(p).all()
+    e = priors.PriorGenerator(64, "face", "ellipsoid")(img, device="cpu")
+    assert abs(e.max().item() - 1.02) < 1e-6 and 0.90 < e.min().item() < 0.93   # near = 0.91
+    assert e[0, 32, 32] < e[0, 32, 12]                                            # dome
+    s = priors.PriorGenerator(64, "face", "smoothed_box")(img, device="cpu")
+    assert abs(s.max().item() - 1.02) < 1e-5 and abs(s.min().item() - 0.91) < 1e-5
+
+
+# ----------------------------------------------------------------------------- reference (live)
+def _ref_sg2():
+    if SG2 not in sys.path:
+        sys.path.insert(0, SG2)
+    import model as ref_sg2
+    return ref_sg2
+
+
+@needs_ref
+def test_small_nets_equal_reference():
+    sys.path.insert(0, REF)
+    from GAN2Shape import networks as ref
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 128, 128)
+    for name in ["DepthNet", "AlbedoNet", "ViewpointNet", "LightingNet", "OffsetEncoder"]:
+        r = getattr(ref, name)(128)
+        m = getattr(networks, name)(128)
+        m.load_state_dict(r.state_dict(), strict=True)
+        with torch.no_grad():
+            torch.testing.assert_close(m(x), r(x), rtol=0, atol=0)
+    m64 = networks.OffsetEncoder(64)
+    assert m64(torch.randn(1, 3, 64, 64)).shape == (1, 512)
+
+
+@needs_ref
+@pytest.mark.parametrize("size,cm", [(128, 1), (64, 2)])
+def test_stylegan2_state_dict_compatible(size, cm):
+    ref = _ref_sg2()
+    from gan2shape_amd import stylegan2 as sg2
+    for cls, args in (("Generator", (size, 512, 8)), ("Discriminator", (size,))):
+        r = getattr(ref, cls)(*args, channel_multiplier=cm)
+        m = getattr(sg2, cls)(*args, channel_multiplier=cm)
+        rs, ms = r.state_dict(), m.state_dict()
+        assert list(rs.keys()) == list(ms.keys())
+        assert all(rs[k].shape == ms[k].shape for k in rs)
+        m.load_state_dict(rs, strict=True)
+
+
+@needs_ref
+def test_lpips_state_dict_keys_match_reference_weight_file():
+    from gan2shape_amd.lpips import PerceptualLoss
+    path = os.path.join(SG2, "lpips/weights/v0.1/vgg.pth")
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    p = PerceptualLoss()
+    own = p.net.state_dict()
+    assert set(sd) <= set(own) and all(sd[k].shape == own[k].shape for k in sd)
+    p.load_lin_weights(path)
+    torch.testing.assert_close(p.net.lin3.model[1].weight, sd["lin3.model.1.weight"])
+    # the metric itself (plain torch, runs on CPU): identical inputs -> 0, symmetric
+    torch.manual_seed(0)
+    a, b = torch.rand(1, 3, 32, 32) * 2 - 1, torch.rand(1, 3, 32, 32) * 2 - 1
+    assert p(a, a).abs().max() == 0
+    torch.testing.assert_close(p(a, b), p(b, a))
+    assert p(a, b).shape == (1, 1, 1, 1) and p(a, b).item() > 0
+
+
+# ----------------------------------------------------------------------------- sharding
+def test_shard_indices_partition():
+    from gan2shape_amd.trainer import shard_indices
+    for n, w in [(8, 1), (8, 2), (32, 4), (5, 8), (7, 3)]:
+        shards = [shard_indices(n, r, w) for r in range(w)]
+        assert sorted(i for s in shards for i in s) == list(range(n))
+        assert shards[0][:2] == [0, w][:len(shards[0][:2])]
