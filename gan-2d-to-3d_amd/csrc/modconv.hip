@@ -26,7 +26,6 @@ namespace g2s {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
 constexpr int NTHREADS = 256;
 
 struct ConvClass {  // one output-parity class (a single class for gather geometries)
@@ -47,30 +46,48 @@ struct ConvDesc {
     int os;              // output stride of a class (1, or 2 for the polyphase classes)
     int ncls;
     int splitk;
+    int w_bytes;         // size of w in bytes (buffer-resource range)
     ConvClass cls[4];
 };
 
+// K tiles hold WHOLE reduction channels (T taps each): 2 channels x 9 taps = 18 for 3x3, else 16.
+// A thread's elements of a tile then keep the same (channel-in-tile, tap) for the entire K loop,
+// so tap offsets, bounds checks and LDS addresses are computed ONCE; per tile only the channel base
+// moves.  This keeps the VALU work per tile (~60 instructions) far below the MFMA time.
+constexpr int BK_MAX = 18;
+template <int T> struct KTile { static constexpr int BKT = (T == 9) ? 18 : 16; static constexpr int CPT = BKT / T; };
+
 template <int BM, int BN, int T>
 __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass &c,
-                                             float (&As)[2][BK][BM + 1], float (&Bs)[2][BK][BN],
-                                             const int (&stab)[9]) {
+                                             float (&As)[2][BK_MAX][BM + 1],
+                                             float (&Bs)[2][BK_MAX + 1][BN], const int (&stab)[9]) {
+    constexpr int BKT = KTile<T>::BKT, CPT = KTile<T>::CPT;
     constexpr int WMT = BM / 64, WNT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
-    constexpr int EA = BM * BK / NTHREADS, EB = BN * BK / NTHREADS;
+    constexpr int EA = (BM * BKT + NTHREADS - 1) / NTHREADS, EB = (BN * BKT + NTHREADS - 1) / NTHREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int Ncls = d.B * c.OH * c.OW;
     const int tiles_m = (d.M + BM - 1) / BM;
     const int m0 = (blockIdx.x % tiles_m) * BM;
     const int n0 = (blockIdx.x / tiles_m) * BN;
-    const int Kc = d.Cr * T;
-    const int ktiles = (Kc + BK - 1) / BK;
+    const int ktiles = (d.Cr + CPT - 1) / CPT;
     const int per = (ktiles + d.splitk - 1) / d.splitk;
     const int kt_begin = blockIdx.y * per;
     const int kt_end = min(ktiles, kt_begin + per);
+    const int HW = d.H * d.W;
+    constexpr int OOB = 0x7fffffff;  // voffset beyond num_records: the buffer load returns 0
 
-    // ---- this thread's im2col column (fixed over the K loop)
+    // Buffer resources (SGPR descriptors built from kernel arguments only): 32-bit per-lane byte
+    // offsets that stay CONSTANT over the K loop + a scalar offset for the channel base; the
+    // hardware range check zeroes masked elements, so the K loop carries no address arithmetic.
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, d.B * d.Cr * HW * 4, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)d.w, 0, d.w_bytes, 0x00020000);
+    const bool has_scale = d.in_scale != nullptr;
+    const auto rsc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_scale ? d.in_scale : d.w), 0, has_scale ? d.B * d.Cr * 4 : 4, 0x00020000);
+
+    // ---- im2col elements of this thread: column n fixed, rows k_e = tid / BN + e * (256 / BN)
     const int nB = tid % BN;
-    const int kB0 = tid / BN;  // + e * (NTHREADS / BN)
     const int ng = n0 + nB;
     const bool n_ok = ng < Ncls;
     int bb = 0, iy0 = 0, ix0 = 0;
@@ -80,46 +97,55 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
         iy0 = (r / c.OW) * d.is;
         ix0 = (r % c.OW) * d.is;
     }
-    const float *xb = d.x + (size_t)bb * d.Cr * d.H * d.W;
-    const float *sb = d.in_scale ? d.in_scale + (size_t)bb * d.Cr : nullptr;
-    // ---- this thread's weight elements: lanes run along k (contiguous taps)
-    const int kA = tid % BK;
-    const int mA0 = tid / BK;  // + e * (NTHREADS / BK)
+    int offB[EB], offS[EB], dchB[EB];
+#pragma unroll
+    for (int e = 0; e < EB; e++) {
+        const int k = tid / BN + e * (NTHREADS / BN);
+        const int dch = k / T, t = k - dch * T;
+        const int tb = stab[t < T ? t : 0];
+        const int iy = iy0 + (tb & 0xff) - 8, ix = ix0 + ((tb >> 8) & 0xff) - 8;
+        const bool ok = n_ok && k < BKT && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+        offB[e] = ok ? (((bb * d.Cr + dch) * d.H + iy) * d.W + ix) * 4 : OOB;
+        offS[e] = ok ? (bb * d.Cr + dch) * 4 : OOB;
+        dchB[e] = dch;
+    }
+    // ---- weight elements: idx = tid + e * 256 -> k = idx % BKT (lanes along contiguous taps)
+    int offA[EA], ldsA[EA], dchA[EA];
+#pragma unroll
+    for (int e = 0; e < EA; e++) {
+        const int idx = tid + e * NTHREADS;
+        const int k = idx % BKT, m = idx / BKT;
+        const int dch = k / T, t = k - dch * T;
+        const bool ok = idx < BM * BKT && m0 + m < d.M;
+        offA[e] = ok ? ((m0 + m) * d.w_ms + dch * d.w_ks + (stab[t] >> 16)) * 4 : OOB;
+        ldsA[e] = (idx < BM * BKT) ? k * (BM + 1) + m : BM;  // surplus elements land in the row padding
+        dchA[e] = dch;
+    }
+    const bool partial = (d.Cr % CPT) != 0;  // only then can a tile run past the last channel
 
-    float ra[EA], rb[EB];
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int e = 0; e < EA; e++) {
-            const int m = m0 + mA0 + e * (NTHREADS / BK);
-            const int kg = kt * BK + kA;
-            float v = 0.0f;
-            if (m < d.M && kg < Kc) {
-                const int ch = kg / T, t = kg - ch * T;
-                v = d.w[(size_t)m * d.w_ms + (size_t)ch * d.w_ks + (stab[t] >> 16)];
-            }
-            ra[e] = v;
-        }
-#pragma unroll
-        for (int e = 0; e < EB; e++) {
-            const int kg = kt * BK + kB0 + e * (NTHREADS / BN);
-            float v = 0.0f;
-            if (n_ok && kg < Kc) {
-                const int ch = kg / T, t = kg - ch * T;
-                const int tb = stab[t];
-                const int iy = iy0 + (tb & 0xff) - 8, ix = ix0 + ((tb >> 8) & 0xff) - 8;
-                if (iy >= 0 && iy < d.H && ix >= 0 && ix < d.W) {
-                    v = xb[((size_t)ch * d.H + iy) * d.W + ix];
-                    if (sb) v *= sb[ch];
-                }
-            }
-            rb[e] = v;
-        }
+    // Software pipeline, one barrier per K tile:
+    //   registers hold tile t+1 (loads issued one iteration earlier), LDS buffer t&1 is being
+    //   multiplied, buffer (t+1)&1 is free.  Inside the MFMA sequence of tile t, after each k-step,
+    //   one A element and one B element of tile t+1 are written to the free buffer and their
+    //   registers are immediately re-loaded with tile t+2 — the staging LDS / VMEM work issues in
+    //   the shadow of the 64-cycle MFMAs instead of in a phase of its own.
+    float ra[EA], rb[EB], rs[EB];
+    auto loadA = [&](int e, int kt) {
+        const int ch0 = kt * CPT;
+        const int vo = (partial && dchA[e] >= d.Cr - ch0) ? OOB : offA[e];
+        ra[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, vo, ch0 * d.w_ks * 4, 0));
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int e = 0; e < EA; e++) As[buf][kA][mA0 + e * (NTHREADS / BK)] = ra[e];
-#pragma unroll
-        for (int e = 0; e < EB; e++) Bs[buf][kB0 + e * (NTHREADS / BN)][nB] = rb[e];
+    auto loadB = [&](int e, int kt) {
+        const int ch0 = kt * CPT;
+        const bool out = partial && dchB[e] >= d.Cr - ch0;
+        rb[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, out ? OOB : offB[e], ch0 * HW * 4, 0));
+        if (has_scale)
+            rs[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, out ? OOB : offS[e], ch0 * 4, 0));
+    };
+    auto storeA = [&](int e, float *abuf) { abuf[ldsA[e]] = ra[e]; };
+    auto storeB = [&](int e, float (*bbuf)[BN]) {
+        const int k = tid / BN + e * (NTHREADS / BN);
+        bbuf[k < BKT ? k : BK_MAX][nB] = has_scale ? rb[e] * rs[e] : rb[e];  // row BK_MAX = dump row
     };
 
     f32x16 acc[WMT][WNT];
@@ -130,30 +156,49 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    load_tile(kt_begin);
-    store_tile(0);
+    const int kt_last = kt_end - 1;
+    // prologue: tile kt_begin -> LDS buffer 0, tile kt_begin+1 -> registers
+#pragma unroll
+    for (int e = 0; e < EA; e++) loadA(e, kt_begin);
+#pragma unroll
+    for (int e = 0; e < EB; e++) loadB(e, kt_begin);
+#pragma unroll
+    for (int e = 0; e < EA; e++) { storeA(e, &As[0][0][0]); loadA(e, min(kt_begin + 1, kt_last)); }
+#pragma unroll
+    for (int e = 0; e < EB; e++) { storeB(e, Bs[0]); loadB(e, min(kt_begin + 1, kt_last)); }
     __syncthreads();
     const int l31 = lane & 31, lk = lane >> 5;
-    for (int kt = kt_begin; kt < kt_end; kt++) {
-        const int buf = (kt - kt_begin) & 1;
-        const bool more = kt + 1 < kt_end;
-        if (more) load_tile(kt + 1);  // global loads in flight during the MFMAs below
+
+    // one K tile: multiply buffer `cur`, stage tile kt+1 into `cur ^ 1`, fetch tile kt+2
+    auto ktile = [&](int kt, const int cur) {
+        const int kt2 = min(kt + 2, kt_last);
+        float *anext = &As[cur ^ 1][0][0];
+        float(*bnext)[BN] = Bs[cur ^ 1];
 #pragma unroll
-        for (int k2 = 0; k2 < BK; k2 += 2) {
+        for (int st = 0; st < BKT / 2; st++) {
+            const int k2 = 2 * st;
             float a[WMT], b[WNT];
 #pragma unroll
-            for (int i = 0; i < WMT; i++) a[i] = As[buf][k2 + lk][wm * (BM / 2) + i * 32 + l31];
+            for (int i = 0; i < WMT; i++) a[i] = As[cur][k2 + lk][wm * (BM / 2) + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < WNT; j++) b[j] = Bs[buf][k2 + lk][wn * (BN / 2) + j * 32 + l31];
+            for (int j = 0; j < WNT; j++) b[j] = Bs[cur][k2 + lk][wn * (BN / 2) + j * 32 + l31];
 #pragma unroll
             for (int i = 0; i < WMT; i++)
 #pragma unroll
                 for (int j = 0; j < WNT; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            // staging slice of this k-step (the other buffer is free; harmless on the last tile)
+            if (st < EA) { storeA(st, anext); loadA(st, kt2); }
+            if (st < EB) { storeB(st, bnext); loadB(st, kt2); }
         }
-        if (more) store_tile(buf ^ 1);
         __syncthreads();
+    };
+    int kt = kt_begin;
+    for (; kt + 1 < kt_end; kt += 2) {  // unrolled by two: LDS buffer indices are compile-time
+        ktile(kt, 0);
+        ktile(kt + 1, 1);
     }
+    if (kt < kt_end) ktile(kt, 0);
 
     // ---- epilogue: C[m][n], m = (r&3) + 8*(r>>2) + 4*(lane>>5), n = lane&31 within a 32x32 tile
 #pragma unroll
@@ -180,21 +225,26 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
     }
 }
 
+static __host__ __device__ inline int ktiles_of(int Cr, int T) {
+    const int cpt = (T == 9) ? 2 : 16 / T;
+    return (Cr + cpt - 1) / cpt;
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
-    __shared__ float As[2][BK][BM + 1];
-    __shared__ float Bs[2][BK][BN];
+    __shared__ float As[2][BK_MAX][BM + 1];
+    __shared__ float Bs[2][BK_MAX + 1][BN];
     __shared__ int stab[9];
     const ConvClass &c = d.cls[blockIdx.z];
     // uniform early exits: smaller parity classes need fewer tiles; empty split-K slices
     const int tiles_m = (d.M + BM - 1) / BM;
     if ((int)(blockIdx.x / tiles_m) * BN >= d.B * c.OH * c.OW) return;
-    const int ktiles = (d.Cr * c.T + BK - 1) / BK;
+    const int ktiles = ktiles_of(d.Cr, c.T);
     const int per = (ktiles + d.splitk - 1) / d.splitk;
     if ((int)blockIdx.y * per >= ktiles) return;
     if (threadIdx.x < 9) stab[threadIdx.x] = c.tab[threadIdx.x];
     __syncthreads();
-    switch (c.T) {  // compile-time tap count: k / T becomes a multiply-shift
+    switch (c.T) {  // compile-time tap count
     case 9: modconv_body<BM, BN, 9>(d, c, As, Bs, stab); break;
     case 4: modconv_body<BM, BN, 4>(d, c, As, Bs, stab); break;
     case 2: modconv_body<BM, BN, 2>(d, c, As, Bs, stab); break;
@@ -230,6 +280,7 @@ extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale
     d.M = transpose ? Cin : Cout;
     d.w_ms = transpose ? KK : Cin * KK;
     d.w_ks = transpose ? Cin * KK : KK;
+    d.w_bytes = Cout * Cin * KK * 4;
     // geometry: gather (stride 1 or 2) or polyphase scatter
     const bool scatter = (mode == G2S_CONV_UP2 && !transpose) || (mode == G2S_CONV_DOWN2 && transpose);
     if (!scatter) {
@@ -276,28 +327,34 @@ extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale
                         c.tab[c.T++] = pack((py - ky) / 2, (px - kx) / 2, ky * k + kx);
             }
     }
-    // tile configuration + split-K: aim for >= 2 workgroups per CU
+    // tile configuration + split-K: aim for >= 2 workgroups (8 waves) per CU
     long nmax = 0;
-    int tmin = 9;
+    int kt_min = 1 << 30;
     for (int i = 0; i < d.ncls; i++) {
         nmax = std::max(nmax, (long)B * d.cls[i].OH * d.cls[i].OW);
-        tmin = std::min(tmin, d.cls[i].T);
+        kt_min = std::min(kt_min, ktiles_of(d.Cr, d.cls[i].T));
     }
-    G2S_REQUIRE(nmax < (1l << 30), "problem too large");
+    G2S_REQUIRE(nmax < (1l << 30) && (long)B * d.Cr * H * W < (1l << 29) && (long)Cout * Cin * KK < (1l << 29),
+                "problem too large for 32-bit byte offsets");
     hipStream_t st = as_stream(stream);
-    const bool big = d.M >= 128 && nmax >= 128 * 64;
-    const int BMv = big ? 128 : 64, BNv = big ? 128 : 64;
+    const int cfgs[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    int pick = 2;
+    for (int i = 0; i < 3; i++) {
+        const long blocks = (long)cdiv(d.M, cfgs[i][0]) * cdiv(nmax, cfgs[i][1]) * d.ncls;
+        if (d.M > cfgs[i][0] / 2 && blocks >= 512) { pick = i; break; }
+    }
+    const int BMv = cfgs[pick][0], BNv = cfgs[pick][1];
     const int tiles = cdiv(d.M, BMv) * cdiv(nmax, BNv);
-    const int ktiles_min = cdiv((long)d.Cr * tmin, BK);
     int splitk = 1;
-    while (tiles * d.ncls * splitk < 256 && splitk * 2 <= ktiles_min / 4 && splitk < 64) splitk *= 2;
+    while ((long)tiles * d.ncls * splitk < 512 && kt_min / (splitk * 2) >= 8 && splitk < 64) splitk *= 2;
     d.splitk = splitk;
     if (splitk > 1) {
         if (hipMemsetAsync(y, 0, (size_t)B * d.M * d.OHf * d.OWf * sizeof(float), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
     }
     dim3 grid(tiles, splitk, d.ncls);
-    if (big) modconv_kernel<128, 128><<<grid, NTHREADS, 0, st>>>(d);
+    if (pick == 0) modconv_kernel<128, 128><<<grid, NTHREADS, 0, st>>>(d);
+    else if (pick == 1) modconv_kernel<128, 64><<<grid, NTHREADS, 0, st>>>(d);
     else modconv_kernel<64, 64><<<grid, NTHREADS, 0, st>>>(d);
     return check_launch("g2s_modconv");
 }

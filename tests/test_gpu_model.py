@@ -52,7 +52,7 @@ def test_mapping_network_golden(sg2, golden):
         for i in range(1, 5):
             G.style[i].weight.copy_(torch.tensor(g[f"style.{i}.weight"]))
             G.style[i].bias.copy_(torch.tensor(g[f"style.{i}.bias"]))
-    G = G.cuda()
+    G = G.cuda().requires_grad_(False)
     z = dev(g["style.z"])
     np.testing.assert_allclose(G.style_forward(z).cpu().numpy(), g["style.full"], rtol=1e-5, atol=1e-6)
     d3 = G.style_forward(z, depth=3)
@@ -185,7 +185,8 @@ def test_step2_is_reproducible_under_a_seed(trainer):
         torch.manual_seed(7)
         loss, _ = m.forward_step2(image, latent, col1, n_proj_samples=3)
         vals.append(loss.item())
-    assert vals[0] == vals[1]
+    # same random draws; split-K float atomics in the small modconv layers reorder sums
+    assert abs(vals[0] - vals[1]) < 1e-5 * abs(vals[0])
 
 
 def test_trainer_fit_and_checkpoint_roundtrip(trainer, tmp_path):
