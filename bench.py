@@ -90,6 +90,24 @@ class StepRunner:
         return loss
 
 
+class GraphedRunner:
+    """Same interface as StepRunner, one hipGraph replay per iteration."""
+
+    def __init__(self, graphed):
+        self.g = graphed
+        self.kind_ms = {1: [], 2: [], 3: []}
+
+    def run(self, kind, timed=False):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        loss = self.g.run(kind)
+        if timed:
+            e1.record()
+            self.kind_ms[kind].append((e0, e1))
+        return loss
+
+
 def cpu_baseline(n_proj):
     """Oracle ("port") timings of the native hot ops on the host cores, bounded to ~10-30 s, scaled
     to aggregate iterations / second.  Covers the custom-kernel share of an iteration only (the
@@ -138,8 +156,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n-proj", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graphs)")
+    ap.add_argument("--only", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="analysis only: time a single step kind instead of the 7:7:6 mix")
     args = ap.parse_args()
 
+    global PATTERN
+    if args.only:
+        PATTERN = [args.only]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -150,6 +174,9 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # All work runs on one non-default stream: an eager backward on the legacy default stream makes
+    # a later HIP-graph capture of the same autograd nodes fail (cross-stream AccumulateGrad sync).
+    torch.cuda.set_stream(torch.cuda.Stream(device))
 
     import gan2shape_amd  # noqa: F401
     from gan2shape_amd import lib, modconv as mc
@@ -159,7 +186,7 @@ def main():
 
     torch.manual_seed(0)  # identical random-init weights on every rank
     cfg = face_config(args.n_proj)
-    trainer = Trainer(GAN2Shape, cfg, device=device)
+    trainer = Trainer(GAN2Shape, cfg, device=device, capturable=not args.eager)
     image, latent = synthetic_sample(trainer.model, 1234 + rank, device)
     torch.manual_seed(1234 + rank)
     runner = StepRunner(trainer, image, latent)
@@ -168,6 +195,15 @@ def main():
     # hand-offs the trainer would have at this point, and triggers lazy library initialisation
     for kind in (1, 2, 3):
         runner.run(kind)
+    eager_runner = runner
+    if not args.eager:
+        # record each step kind into a HIP graph; a replay is one training iteration
+        from gan2shape_amd.graphs import GraphedSteps
+        graphed = GraphedSteps(trainer, image, latent)
+        graphed.collected = dict(runner.collected)
+        for kind in (1, 2, 3):
+            graphed.capture(kind)
+        runner = GraphedRunner(graphed)
     for i in range(args.warmup):
         runner.run(PATTERN[i % len(PATTERN)])
 
@@ -177,13 +213,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    mc.PROFILE = []  # (flops, start event, end event) per g2s_modconv launch, on its stream
+    # (flops, start event, end event) per g2s_modconv launch, recorded on its launch stream.
+    # Eager mode: recorded inside the timed region.  Graph mode: HIP events cannot be recorded
+    # between the nodes of a replayed graph, so the same launches are timed in an eager pass of
+    # one 20-step cycle right after the timed region (same process, same shapes, same kernels).
+    mc.PROFILE = [] if args.eager else None
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         runner.run(PATTERN[i % len(PATTERN)], timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
+    if not args.eager:
+        mc.PROFILE = []
+        for kind in PATTERN:
+            eager_runner.run(kind)
+        torch.cuda.synchronize()
     prof, mc.PROFILE = mc.PROFILE, None
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -202,7 +247,9 @@ def main():
                     "kernel": "g2s::modconv_kernel (fp32 MFMA implicit GEMM)",
                     "launches": len(prof), "avg_launch_us": (ms * 1e3 / len(prof)) if prof else None,
                     "gflop_per_launch": (flops / 1e9 / len(prof)) if prof else None,
-                    "share_of_timed_region": ms * 1e-3 / elapsed}
+                    "timed_by": "hip events around each launch, " + (
+                        "inside the timed region" if args.eager else
+                        "eager pass of one 20-step cycle after the graph-replayed timed region")}
         out = {
             "metric": "GAN2Shape step iters/sec, faces 128x128 b=8",
             "value": world * args.steps / elapsed, "unit": "iters/s", "n_gpus": world,
@@ -211,9 +258,11 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "face128_n8" if args.n_proj == 8 else f"face128_n{args.n_proj}",
                        "image_size": 128, "gan_size": 128, "n_proj_samples": args.n_proj,
-                       "step_mix": "7:7:6 (step1:step2:step3, main.py:148 stage 0)",
+                       "step_mix": "7:7:6 (step1:step2:step3, main.py:148 stage 0)" if not args.only
+                       else f"step{args.only} only (analysis run, not the BASELINE metric)",
                        "images_per_rank": 1, "sharding": "one image per rank, no collective"},
             "ms_per_step_kind": {f"step{k}": v for k, v in kind_ms.items()},
+            "launch_mode": "eager" if args.eager else "hipGraph replay (one graph per step kind)",
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -55,6 +55,14 @@ class Renderer():
         self._centroid = torch.tensor([0., 0., self.rot_center_depth], device=self.device).view(1, 1, 3)
         self._rays = {}
 
+    def _const(self, key, make):
+        """Device constants are built once: a host->device copy inside the hot loop would also make
+        the iteration impossible to record into a HIP graph."""
+        v = self._rays.get(key)
+        if v is None:
+            v = self._rays[key] = make()
+        return v
+
     def set_transform_matrices(self, view):
         self.rot_mat, self.trans_xyz = get_transform_matrices(view)
 
@@ -86,7 +94,8 @@ class Renderer():
         b, h, w, _ = grid_3d.shape
         grid_2d = grid_3d / grid_3d[..., 2:]
         grid_2d = grid_2d.matmul(self.K.to(grid_3d.device).transpose(2, 1))[:, :, :, :2]
-        WH = torch.tensor([w - 1, h - 1], dtype=torch.float32, device=grid_3d.device).view(1, 1, 1, 2)
+        WH = self._const(("wh", h, w, str(grid_3d.device)), lambda: torch.tensor(
+            [w - 1, h - 1], dtype=torch.float32, device=grid_3d.device).view(1, 1, 1, 2))
         return grid_2d / WH * 2. - 1.  # normalize to -1~1
 
     def get_warped_3d_grid(self, depth):
@@ -126,9 +135,12 @@ class Renderer():
         normal = torch.linalg.cross(tu, tv, dim=3)
         # border pixels get (0, 0, 1)
         normal = nn.functional.pad(normal.permute(0, 3, 1, 2), (1, 1, 1, 1)).permute(0, 2, 3, 1)
-        border = torch.ones(1, h, w, 1, device=depth.device)
-        border[:, 1:-1, 1:-1] = 0
-        normal = normal + border * torch.tensor([0., 0., 1.], device=depth.device)
+        def make_border():
+            border = torch.zeros(1, h, w, 3, device=depth.device)
+            border[..., 2] = 1
+            border[:, 1:-1, 1:-1] = 0
+            return border
+        normal = normal + self._const(("border", h, w, str(depth.device)), make_border)
         return normal / (((normal ** 2).sum(3, keepdim=True)) ** 0.5 + EPS)
 
     def render_given_view(self, im, depth, view, mask=None, grid_sample=True):

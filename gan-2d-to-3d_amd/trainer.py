@@ -27,7 +27,8 @@ def shard_indices(n_items, rank, world_size):
 
 class Trainer():
     def __init__(self, model, model_config, debug=False, plot_intermediate=False, log_wandb=False,
-                 save_ckpts=False, load_dict=None, masking_model=None, device="cuda"):
+                 save_ckpts=False, load_dict=None, masking_model=None, device="cuda",
+                 capturable=False):
         try:
             self.model = model(model_config, debug, device=device)
         except TypeError:  # a model class with the reference's exact (config, debug) signature
@@ -41,16 +42,19 @@ class Trainer():
         self.learning_rate = model_config.get('learning_rate', 1e-4)
         self.save_ckpts = save_ckpts
         self.debug = debug
+        self.capturable = capturable  # Adam(capturable=True): needed to record steps in HIP graphs
         self.prior_generator = PriorGenerator(self.image_size, self.category,
                                               model_config.get('prior_name', 'ellipsoid'),
                                               masking_model=masking_model)
-        self.optim_step1 = Trainer.default_optimizer([self.model.albedo_net], lr=self.learning_rate)
+        self.optim_step1 = Trainer.default_optimizer([self.model.albedo_net], lr=self.learning_rate,
+                                                     capturable=capturable)
         self.optim_step2 = Trainer.default_optimizer([self.model.offset_encoder_net],
-                                                     lr=self.learning_rate)
+                                                     lr=self.learning_rate, capturable=capturable)
         self.optim_step3 = Trainer.default_optimizer([self.model.lighting_net,
                                                       self.model.viewpoint_net,
                                                       self.model.depth_net,
-                                                      self.model.albedo_net], lr=self.learning_rate)
+                                                      self.model.albedo_net], lr=self.learning_rate,
+                                                     capturable=capturable)
         self.load_dict = load_dict
         if load_dict is not None:
             paths, _ = self.model.build_checkpoint_path(load_dict['base_path'],
@@ -111,8 +115,10 @@ class Trainer():
         return [float(v) for v in torch.stack(losses).cpu()] if losses else []
 
     @staticmethod
-    def default_optimizer(model_list, lr=1e-4, betas=(0.9, 0.999), weight_decay=5e-4):
+    def default_optimizer(model_list, lr=1e-4, betas=(0.9, 0.999), weight_decay=5e-4,
+                          capturable=False):
         param_list = []
         for model in model_list:
             param_list += [p for p in model.parameters() if p.requires_grad]
-        return torch.optim.Adam(param_list, lr=lr, betas=betas, weight_decay=weight_decay)
+        return torch.optim.Adam(param_list, lr=lr, betas=betas, weight_decay=weight_decay,
+                                capturable=capturable)
