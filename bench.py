@@ -108,45 +108,54 @@ class GraphedRunner:
         return loss
 
 
+def _repeat(fn, min_seconds):
+    """Run fn until `min_seconds` of wall time have been spent; returns (seconds per call, calls)."""
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds:
+            return dt / n, n
+
+
 def cpu_baseline(n_proj):
-    """Oracle ("port") timings of the native hot ops on the host cores, bounded to ~10-30 s, scaled
-    to aggregate iterations / second.  Covers the custom-kernel share of an iteration only (the
-    modulated convolutions of the generator pass and the rasterizer), so it over-states CPU speed."""
+    """Oracle ("port") timings of the native hot ops on the host cores: ~10 s of modulated
+    convolution + ~10 s of brute-force rasterization (the reference algorithm), scaled to
+    aggregate iterations / second.  Covers the custom-kernel share of an iteration only (the
+    modulated convolutions of the generator pass and the rasterizer; the MIOpen-side networks are
+    not restated on the CPU), so it over-states the CPU's speed on the full iteration."""
     import numpy as np
     from oracle import capi
     from oracle import geometry as og
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     rng = np.random.default_rng(0)
-    # (a) one modulated conv, 128 -> 128 channels at 64x64, B = 1: 2*128*128*9*4096 = 1.2 GFLOP
-    x = rng.standard_normal((1, 128, 64, 64)).astype(np.float32)
-    w = rng.standard_normal((128, 128, 3, 3)).astype(np.float32)
-    s = np.ones((1, 128), np.float32)
-    capi.modconv(x[:, :, :8, :8], w, s, 1.0, True, 0)
-    t0 = time.perf_counter()
-    capi.modconv(x, w, s, 1.0, True, 0)
-    t_conv = time.perf_counter() - t0
-    gflop_sample = 2 * 128 * 128 * 9 * 64 * 64 / 1e9
+    # (a) convs[5] of the generator: 512 -> 512 channels at 32x32, B = 1: 4.83 GFLOP
+    x = rng.standard_normal((1, 512, 32, 32)).astype(np.float32)
+    w = rng.standard_normal((512, 512, 3, 3)).astype(np.float32)
+    s = np.ones((1, 512), np.float32)
+    capi.modconv(x[:, :, :4, :4], w, s, 1.0, True, 0)
+    t_conv, n_conv = _repeat(lambda: capi.modconv(x, w, s, 1.0, True, 0), 10.0)
+    gflop_sample = 2 * 512 * 512 * 9 * 32 * 32 / 1e9
     # generator forward 22.52 GFLOP / image (SURVEY §8a), forward + data-gradient, n_proj images
-    gflop_step2 = 22.52 * n_proj * 2
-    t_step2 = t_conv * gflop_step2 / gflop_sample
-    # (b) brute-force rasterizer (the reference algorithm), one 128x128 image
+    t_step2 = t_conv * (22.52 * n_proj * 2) / gflop_sample
+    # (b) brute-force rasterizer, one 128x128 image per call
     S = 128
     geo = og.Geometry(S)
     geo.set_transform_matrices(np.array([[0.2, -0.3, 0.05, 0.01, 0.02, -0.03]], np.float32))
     depth = (1.0 + 0.05 * np.sin(np.arange(S)[None, :, None] / 9.0) * np.ones((1, S, S))).astype(np.float32)
     verts = geo.get_warped_3d_grid(depth).reshape(1, -1, 3)
     faces = og.get_face_idx(1, S, S)[0]
-    t0 = time.perf_counter()
-    capi.render_depth(verts, faces, S, geo.K[0])
-    t_raster = time.perf_counter() - t0
+    t_raster, n_raster = _repeat(lambda: capi.render_depth(verts, faces, S, geo.K[0]), 10.0)
     # rasterized images per iteration: step 1: 1, step 2: n, step 3: 1 + n
     t1, t2, t3 = t_raster, t_step2 + n_proj * t_raster, (1 + n_proj) * t_raster
     its = 20.0 / (7 * t1 + 7 * t2 + 6 * t3)
     return {"value": its, "unit": "iters/s", "cores": cores, "kind": "port",
-            "sample": f"oracle modconv 128->128@64x64 B=1 ({t_conv:.2f}s, scaled by GFLOP to the "
-                      f"generator fwd+bwd of step 2) + brute-force raster of one 128x128 image "
-                      f"({t_raster:.2f}s, scaled by images/iteration); custom-kernel share only"}
+            "sample": f"{n_conv} x oracle modconv 512->512@32x32 B=1 ({t_conv:.3f} s each, scaled by "
+                      f"GFLOP to the generator fwd+bwd of step 2) + {n_raster} x brute-force raster of "
+                      f"one 128x128 image ({t_raster:.3f} s each, scaled by images/iteration); "
+                      f"custom-kernel share of the iteration only"}
 
 
 def main():
@@ -164,12 +173,9 @@ def main():
     global PATTERN
     if args.only:
         PATTERN = [args.only]
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    import gan2shape_amd  # noqa: F401
+    from gan2shape_amd import sharding
+    rank, world, local_rank = sharding.init_distributed("nccl")
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
@@ -178,7 +184,6 @@ def main():
     # a later HIP-graph capture of the same autograd nodes fail (cross-stream AccumulateGrad sync).
     torch.cuda.set_stream(torch.cuda.Stream(device))
 
-    import gan2shape_amd  # noqa: F401
     from gan2shape_amd import lib, modconv as mc
     from gan2shape_amd.model import GAN2Shape
     from gan2shape_amd.trainer import Trainer
@@ -231,10 +236,8 @@ def main():
         torch.cuda.synchronize()
     prof, mc.PROFILE = mc.PROFILE, None
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    # whole-job rate: iterations of all ranks / the slowest rank's barrier-bracketed time
+    rate, elapsed = sharding.job_throughput(args.steps, elapsed, device)
 
     if rank == 0:
         kind_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None)
@@ -252,7 +255,7 @@ def main():
                         "eager pass of one 20-step cycle after the graph-replayed timed region")}
         out = {
             "metric": "GAN2Shape step iters/sec, faces 128x128 b=8",
-            "value": world * args.steps / elapsed, "unit": "iters/s", "n_gpus": world,
+            "value": rate, "unit": "iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -18,11 +18,7 @@ import torch
 from torch.utils.data import DataLoader, Subset
 
 from .priors import PriorGenerator
-
-
-def shard_indices(n_items, rank, world_size):
-    """Images of rank `rank`: rank, rank + W, rank + 2W, ..."""
-    return list(range(rank, n_items, world_size))
+from .sharding import shard_indices  # noqa: F401  (re-exported)
 
 
 class Trainer():
