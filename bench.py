@@ -175,7 +175,9 @@ def main():
         PATTERN = [args.only]
     import gan2shape_amd  # noqa: F401
     from gan2shape_amd import sharding
-    rank, world, local_rank = sharding.init_distributed("nccl")
+    # RCCL ("nccl") on a multi-GPU node; G2S_DIST_BACKEND=gloo rehearses the N>1 path on one GPU
+    rank, world, local_rank = sharding.init_distributed(os.environ.get("G2S_DIST_BACKEND", "nccl"))
+    local_rank %= max(torch.cuda.device_count(), 1)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
