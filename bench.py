@@ -247,8 +247,17 @@ def main():
         flops = sum(p[0] for p in prof)
         ms = sum(p[1].elapsed_time(p[2]) for p in prof)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        import glob
+        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_modconv_pmc.json")))
+        if pmc:  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command
+            with open(pmc[-1]) as f:
+                traffic = json.load(f)["traffic_bytes_per_launch"]
+            traffic_src = os.path.relpath(pmc[-1], ROOT)
         roofline = {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": (sum(p[3] for p in prof) / len(prof)) if prof else None,
                     "kernel": "g2s::modconv_kernel (fp32 MFMA implicit GEMM)",
                     "launches": len(prof), "avg_launch_us": (ms * 1e3 / len(prof)) if prof else None,
                     "gflop_per_launch": (flops / 1e9 / len(prof)) if prof else None,

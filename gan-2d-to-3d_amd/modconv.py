@@ -68,7 +68,8 @@ def modconv_raw(x, w, in_scale, out_scale, mode, transpose):
         e1.record()
         # algorithmic FLOP: 2 * B * Cout * Cin * k^2 * (spatial positions of the un-strided side)
         sp = min(H * W, oh * ow) if mode != PLAIN else oh * ow
-        prof.append((2.0 * B * Cout * Cin * k * k * sp, e0, e1))
+        nbytes = 4.0 * (x.numel() + w.numel() + y.numel())  # algorithmic: each operand once
+        prof.append((2.0 * B * Cout * Cin * k * k * sp, e0, e1, nbytes))
     return y
 
 
