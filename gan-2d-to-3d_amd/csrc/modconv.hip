@@ -169,27 +169,50 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
     __syncthreads();
     const int l31 = lane & 31, lk = lane >> 5;
 
-    // one K tile: multiply buffer `cur`, stage tile kt+1 into `cur ^ 1`, fetch tile kt+2
+    // one K tile: multiply buffer `cur`, stage tile kt+1 into `cur ^ 1`, fetch tile kt+2.
+    // Operand fragments are register double-buffered (the ds_reads of k-step s+1 are issued before
+    // the MFMAs of step s) and the staging slice is spread BETWEEN the MFMAs of the step, so one
+    // wave alone keeps the matrix pipe issuing back to back; two co-resident waves that run in
+    // lockstep (same program, same phase) then no longer leave the pipe idle together.
     auto ktile = [&](int kt, const int cur) {
         const int kt2 = min(kt + 2, kt_last);
         float *anext = &As[cur ^ 1][0][0];
         float(*bnext)[BN] = Bs[cur ^ 1];
+        float a[2][WMT], b[2][WNT];
+#pragma unroll
+        for (int i = 0; i < WMT; i++) a[0][i] = As[cur][lk][wm * (BM / 2) + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < WNT; j++) b[0][j] = Bs[cur][lk][wn * (BN / 2) + j * 32 + l31];
 #pragma unroll
         for (int st = 0; st < BKT / 2; st++) {
-            const int k2 = 2 * st;
-            float a[WMT], b[WNT];
+            const int p = st & 1, k2n = 2 * st + 2;
+            if (st + 1 < BKT / 2) {
 #pragma unroll
-            for (int i = 0; i < WMT; i++) a[i] = As[cur][k2 + lk][wm * (BM / 2) + i * 32 + l31];
+                for (int i = 0; i < WMT; i++) a[p ^ 1][i] = As[cur][k2n + lk][wm * (BM / 2) + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < WNT; j++) b[j] = Bs[cur][k2 + lk][wn * (BN / 2) + j * 32 + l31];
+                for (int j = 0; j < WNT; j++) b[p ^ 1][j] = Bs[cur][k2n + lk][wn * (BN / 2) + j * 32 + l31];
+            }
+            int slot = 0;
 #pragma unroll
             for (int i = 0; i < WMT; i++)
 #pragma unroll
-                for (int j = 0; j < WNT; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            // staging slice of this k-step (the other buffer is free; harmless on the last tile)
-            if (st < EA) { storeA(st, anext); loadA(st, kt2); }
-            if (st < EB) { storeB(st, bnext); loadB(st, kt2); }
+                for (int j = 0; j < WNT; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][i], b[p][j], acc[i][j], 0, 0, 0);
+                    // staging slice of this k-step, one quarter after each MFMA
+                    if (slot == 0 && st < EA) storeA(st, anext);
+                    if (slot == (WMT * WNT > 1 ? 1 : 0) && st < EA) loadA(st, kt2);
+                    if (slot == (WMT * WNT > 2 ? 2 : 0) && st < EB) storeB(st, bnext);
+                    if (slot == (WMT * WNT > 3 ? 3 : 0) && st < EB) loadB(st, kt2);
+                    slot++;
+                }
+            // pin the interleave: next fragments first, then MFMA / staging alternately
+            __builtin_amdgcn_sched_group_barrier(0x100, WMT + WNT, 0);  // DS read
+            for (int q = 0; q < WMT * WNT; q++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+            }
         }
         __syncthreads();
     };
