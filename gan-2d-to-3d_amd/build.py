@@ -22,6 +22,7 @@ SOURCES = {
     "fused_bias_act.hip": [],
     "upfirdn2d.hip": [],
     "modconv.hip": [],
+    "rowops.hip": [],
     "geometry.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

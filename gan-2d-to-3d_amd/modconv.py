@@ -73,6 +73,60 @@ def modconv_raw(x, w, in_scale, out_scale, mode, transpose):
     return y
 
 
+def rows_dot_scale(a, b, s=None, inv=None, want_out=True, want_dot=True):
+    """Fused row pass (g2s_rows_dot_scale) over [B, C, H, W] tensors viewed as [B*C, H*W]:
+    returns (b * s[r], (sum_hw a * b) / inv[r]) — either may be skipped."""
+    b = b.contiguous()
+    B, C = b.shape[:2]
+    n = b[0, 0].numel()
+    a_ = None if a is None or not want_dot else a.contiguous()
+    out = torch.empty_like(b) if want_out else None
+    dot = torch.empty((B, C), dtype=torch.float32, device=b.device) if want_dot else None
+    s_ = None if s is None else s.contiguous()
+    inv_ = None if inv is None else inv.contiguous()
+    L = _lib.load()
+    _lib.check(L.g2s_rows_dot_scale(_lib.ptr(a_), _lib.ptr(b), _lib.ptr(s_), _lib.ptr(inv_),
+                                    _lib.ptr(out), _lib.ptr(dot), B * C, n, _lib.stream()))
+    return out, dot
+
+
+class DemodFunction(Function):
+    """demod[b,o] = rsqrt(sum_i wsq[o,i] s[b,i]^2 + eps) (model.py:254-258), gradient to s only
+    (wsq belongs to the frozen generator)."""
+
+    @staticmethod
+    def forward(ctx, s, wsq, eps):
+        s = s.contiguous()
+        wsq = wsq.contiguous()
+        B, Cin = s.shape
+        Cout = wsq.shape[0]
+        demod = torch.empty((B, Cout), dtype=torch.float32, device=s.device)
+        L = _lib.load()
+        _lib.check(L.g2s_demod_fwd(_lib.ptr(wsq), _lib.ptr(s), _lib.ptr(demod), B, Cin, Cout,
+                                   float(eps), _lib.stream()))
+        ctx.save_for_backward(s, wsq, demod)
+        return demod
+
+    @staticmethod
+    def backward(ctx, gd):
+        s, wsq, demod = ctx.saved_tensors
+        B, Cin = s.shape
+        gs = torch.empty_like(s)
+        L = _lib.load()
+        _lib.check(L.g2s_demod_bwd(_lib.ptr(wsq), _lib.ptr(s), _lib.ptr(demod),
+                                   _lib.ptr(gd.contiguous()), _lib.ptr(gs), B, Cin, wsq.shape[0],
+                                   _lib.stream()))
+        return gs, None, None
+
+
+def demodulation(s, wsq, eps=1e-8):
+    """Fused kernel when wsq is a constant (frozen generator), torch ops otherwise."""
+    if wsq.requires_grad:
+        return torch.rsqrt(torch.nn.functional.linear(s * s, wsq) + eps)
+    _lib.require_cuda(s, wsq)
+    return DemodFunction.apply(s, wsq, eps)
+
+
 class ModConvFunction(Function):
     @staticmethod
     def forward(ctx, x, w, s, demod, mode):
@@ -91,14 +145,13 @@ class ModConvFunction(Function):
         if ctx.needs_input_grad[0] or (ctx.has_s and ctx.needs_input_grad[2]):
             gxs = modconv_raw(gy, w, demod, None, ctx.mode, 1)  # gradient w.r.t. (s * x)
             if ctx.has_s:
-                if ctx.needs_input_grad[2]:
-                    gs = (x * gxs).sum((2, 3))
-                if ctx.needs_input_grad[0]:
-                    gx = gxs * s[:, :, None, None]
+                # one pass over (x, gxs): gs = sum_hw x * gxs and gx = gxs * s
+                gx, gs = rows_dot_scale(x, gxs, s, None, want_out=ctx.needs_input_grad[0],
+                                        want_dot=ctx.needs_input_grad[2])
             else:
                 gx = gxs
         if ctx.has_d and ctx.needs_input_grad[3]:
-            gd = (gy * y).sum((2, 3)) / demod
+            _, gd = rows_dot_scale(gy, y, None, demod, want_out=False, want_dot=True)
         if ctx.needs_input_grad[1]:
             gw = _weight_grad(x, w, s, demod, gy, ctx.mode)
         return gx, gw, gs, gd, None

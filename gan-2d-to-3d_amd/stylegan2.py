@@ -22,7 +22,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from .modconv import DOWN2, PLAIN, UP2, modconv
+from .modconv import DOWN2, PLAIN, UP2, demodulation, modconv
 from .op import FusedLeakyReLU, fused_leaky_relu, fused_noise_bias_act, upfirdn2d
 
 
@@ -209,7 +209,7 @@ class ModulatedConv2d(nn.Module):
         w, wsq = self._weights()
         demod = None
         if self.demodulate:                             # model.py:256-258
-            demod = torch.rsqrt(F.linear(s * s, wsq) + self.eps)
+            demod = demodulation(s, wsq, self.eps)
         if self.upsample:                               # model.py:264-275
             return self.blur(modconv(input, w, s, demod, UP2))
         if self.downsample:                             # model.py:277-283

@@ -142,6 +142,21 @@ int g2s_modconv(const float *x, const float *w, const float *in_scale, const flo
                 float *y, int B, int Cin, int Cout, int H, int W, int k, int mode, int transpose,
                 g2s_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Row-wise fused reductions around the modulated convolution (csrc/rowops.hip).
+ * g2s_rows_dot_scale: a, b, out are [rows, n] f32; s, inv, dot are [rows].
+ *   dot[r]   = (sum_i a[r,i] * b[r,i]) * (inv ? 1 / inv[r] : 1)      (dot may be NULL; needs a)
+ *   out[r,i] = b[r,i] * s[r]                                          (out may be NULL or alias b)
+ * g2s_demod_fwd: demod[b,o] = rsqrt(sum_i wsq[o,i] * s[b,i]^2 + eps)  (model.py:254-258)
+ * g2s_demod_bwd: gs[b,i] = -s[b,i] * sum_o gd[b,o] * demod[b,o]^3 * wsq[o,i]
+ * ---------------------------------------------------------------------------------------- */
+int g2s_rows_dot_scale(const float *a, const float *b, const float *s, const float *inv, float *out,
+                       float *dot, int rows, int n, g2s_stream_t stream);
+int g2s_demod_fwd(const float *wsq, const float *s, float *demod, int B, int Cin, int Cout,
+                  float eps, g2s_stream_t stream);
+int g2s_demod_bwd(const float *wsq, const float *s, const float *demod, const float *gd, float *gs,
+                  int B, int Cin, int Cout, g2s_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

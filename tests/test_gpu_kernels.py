@@ -280,3 +280,34 @@ def test_modconv_transpose_is_adjoint(g2s, mode, h):
     assert xt.shape == x.shape
     lhs, rhs = (y.double() * g.double()).sum().item(), (x.double() * xt.double()).sum().item()
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
+# ----------------------------------------------------------------------------- row ops
+@pytest.mark.parametrize("shape", [(2, 5, 7, 9), (3, 64, 16, 16), (1, 3, 129, 129), (8, 512, 4, 4)])
+def test_rows_dot_scale(g2s, shape):
+    from gan2shape_amd.modconv import rows_dot_scale
+    torch.manual_seed(0)
+    a, b = torch.randn(*shape, device="cuda"), torch.randn(*shape, device="cuda")
+    s = torch.randn(shape[:2], device="cuda")
+    inv = torch.rand(shape[:2], device="cuda") + 0.5
+    out, dot = rows_dot_scale(a, b, s, inv)
+    torch.testing.assert_close(out, b * s[:, :, None, None], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(dot, (a.double() * b.double()).sum((2, 3)).float() / inv, rtol=1e-4, atol=1e-4)
+    out2, dot2 = rows_dot_scale(a, b, None, None, want_out=False)
+    assert out2 is None
+    torch.testing.assert_close(dot2, (a.double() * b.double()).sum((2, 3)).float(), rtol=1e-4, atol=1e-4)
+
+
+def test_demodulation_matches_torch(g2s):
+    from gan2shape_amd.modconv import demodulation
+    torch.manual_seed(0)
+    for B, cin, cout in [(2, 16, 24), (8, 512, 512), (3, 130, 7)]:
+        s = (torch.randn(B, cin, device="cuda") * 0.5 + 1).requires_grad_(True)
+        wsq = torch.rand(cout, cin, device="cuda") / cin
+        d = demodulation(s, wsq)
+        ref = torch.rsqrt(torch.nn.functional.linear(s * s, wsq) + 1e-8)
+        torch.testing.assert_close(d, ref, rtol=1e-5, atol=1e-6)
+        g = torch.randn_like(d)
+        (gs,) = torch.autograd.grad(d, s, g)
+        (gref,) = torch.autograd.grad(ref, s, g)
+        torch.testing.assert_close(gs, gref, rtol=1e-4, atol=1e-5)
