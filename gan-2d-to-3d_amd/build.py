@@ -23,6 +23,7 @@ SOURCES = {
     "upfirdn2d.hip": [],
     "modconv.hip": [],
     "rowops.hip": [],
+    "lpips.hip": [],
     "geometry.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

@@ -12,6 +12,9 @@ random-initialised (benchmarks / tests), and says so via `.pretrained`.
 """
 import torch
 import torch.nn as nn
+from torch.autograd import Function
+
+from . import lib as _lib
 
 # torchvision.models.vgg16().features layout: conv indices and the pools in front of each slice
 _VGG_SLICES = [
@@ -27,6 +30,34 @@ _POOL_BEFORE = [None, 4, 9, 16, 23]
 def normalize_tensor(in_feat, eps=1e-10):
     norm_factor = torch.sqrt(torch.sum(in_feat ** 2, dim=1, keepdim=True))
     return in_feat / (norm_factor + eps)
+
+
+class _LpipsLayer(Function):
+    """out[n] += mean_hw sum_c w_c (normalize(f0) - normalize(f1))^2 in one kernel (g2s_lpips_layer_*).
+    Gradient w.r.t. f0 only."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, w, acc):
+        f0, f1 = f0.contiguous(), f1.contiguous()
+        N, C, H, W = f0.shape
+        wv = w.reshape(-1).contiguous()
+        L = _lib.load()
+        _lib.check(L.g2s_lpips_layer_fwd(_lib.ptr(f0), _lib.ptr(f1), _lib.ptr(wv), _lib.ptr(acc),
+                                         N, C, H * W, _lib.stream()))
+        ctx.save_for_backward(f0, f1, wv)
+        ctx.mark_dirty(acc)
+        return acc
+
+    @staticmethod
+    def backward(ctx, gout):
+        f0, f1, wv = ctx.saved_tensors
+        N, C, H, W = f0.shape
+        g0 = torch.empty_like(f0)
+        L = _lib.load()
+        _lib.check(L.g2s_lpips_layer_bwd(_lib.ptr(f0), _lib.ptr(f1), _lib.ptr(wv),
+                                         _lib.ptr(gout.contiguous()), _lib.ptr(g0), N, C, H * W,
+                                         _lib.stream()))
+        return g0, None, None, gout
 
 
 class VGG16Features(nn.Module):
@@ -88,12 +119,26 @@ class PNetLin(nn.Module):
         return [normalize_tensor(f) for f in self.net(self.scaling_layer(x))]
 
     def forward(self, in0, in1):
-        f0, f1 = self.features(in0), self.features(in1)
-        val = 0
+        """in0 = target branch, in1 = prediction branch (PerceptualLoss calls forward(target, pred),
+        lpips/__init__.py:39).  On the GPU with a gradient-free target the five per-layer tails run
+        as fused kernels; otherwise the reference's op-by-op form is used (CPU tests, or a target
+        that needs a gradient)."""
+        fused = in0.is_cuda and not in0.requires_grad and not any(
+            getattr(self, f"lin{k}").model[-1].weight.requires_grad for k in range(5))
+        if not fused:
+            f0, f1 = self.features(in0), self.features(in1)
+            val = 0
+            for k in range(5):
+                diff = (f0[k] - f1[k]) ** 2
+                val = val + getattr(self, f"lin{k}").model(diff).mean([2, 3], keepdim=True)
+            return val
+        with torch.no_grad():
+            ft = self.net(self.scaling_layer(in0))
+        fp = self.net(self.scaling_layer(in1))
+        acc = torch.zeros(in1.shape[0], dtype=torch.float32, device=in1.device)
         for k in range(5):
-            diff = (f0[k] - f1[k]) ** 2
-            val = val + getattr(self, f"lin{k}").model(diff).mean([2, 3], keepdim=True)
-        return val
+            acc = _LpipsLayer.apply(fp[k], ft[k], getattr(self, f"lin{k}").model[-1].weight, acc)
+        return acc.view(-1, 1, 1, 1)
 
 
 class PerceptualLoss(nn.Module):

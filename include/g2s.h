@@ -157,6 +157,18 @@ int g2s_demod_fwd(const float *wsq, const float *s, float *demod, int B, int Cin
 int g2s_demod_bwd(const float *wsq, const float *s, const float *demod, const float *gd, float *gs,
                   int B, int Cin, int Cout, g2s_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * LPIPS per-layer tail (csrc/lpips.hip): unit-normalise both feature maps over channels, weighted
+ * squared difference, spatial mean — lpips/networks_basic.py:64-92 + lpips/__init__.py:40-42.
+ * f0, f1 [N, C, HW] f32; w [C] (the 1x1 `lin` weights); out [N] is ACCUMULATED into
+ * (out[n] += mean_hw sum_c w_c (f0n - f1n)^2): zero it before the first layer.
+ * _bwd: g0 [N, C, HW] = d(sum_n gout[n] * out[n]) / d f0   (f1 is the target branch).
+ * ---------------------------------------------------------------------------------------- */
+int g2s_lpips_layer_fwd(const float *f0, const float *f1, const float *w, float *out, int N, int C,
+                        int HW, g2s_stream_t stream);
+int g2s_lpips_layer_bwd(const float *f0, const float *f1, const float *w, const float *gout,
+                        float *g0, int N, int C, int HW, g2s_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

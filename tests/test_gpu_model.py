@@ -215,3 +215,25 @@ def test_trainer_fit_and_checkpoint_roundtrip(trainer, tmp_path):
     for k, v in m.depth_net.state_dict().items():
         torch.testing.assert_close(v, before[k])
     assert set(GAN2Shape.NETS) == {'lighting', 'viewpoint', 'depth', 'albedo', 'offset_encoder'}
+
+
+def test_lpips_fused_tail_matches_reference_form():
+    """g2s_lpips_layer_* vs the op-by-op form of lpips/networks_basic.py:64-92 (same module, the
+    unfused branch is taken when the target requires a gradient)."""
+    import gan2shape_amd  # noqa: F401
+    from gan2shape_amd.lpips import PerceptualLoss
+    torch.manual_seed(0)
+    p = PerceptualLoss().cuda()
+    with torch.no_grad():
+        for k in range(5):
+            getattr(p.net, f"lin{k}").model[-1].weight.uniform_(0.0, 1.0)
+    for B in (1, 3):
+        pred = (torch.rand(B, 3, 64, 64, device="cuda") * 2 - 1).requires_grad_(True)
+        target = torch.rand(B, 3, 64, 64, device="cuda") * 2 - 1
+        fused = p(pred, target)
+        (g_fused,) = torch.autograd.grad(fused.sum(), pred)
+        ref = p(pred, target.clone().requires_grad_(True))
+        (g_ref,) = torch.autograd.grad(ref.sum(), pred)
+        assert fused.shape == ref.shape == (B, 1, 1, 1)
+        torch.testing.assert_close(fused, ref, rtol=2e-5, atol=1e-7)
+        torch.testing.assert_close(g_fused, g_ref, rtol=2e-4, atol=2e-6 * float(g_ref.abs().max()) + 1e-9)
