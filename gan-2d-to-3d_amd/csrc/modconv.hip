@@ -287,8 +287,8 @@ extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale
     G2S_REQUIRE(x && w && y, "x, w, y must not be NULL");
     G2S_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "sizes must be positive");
     G2S_REQUIRE(k == 1 || k == 3, "kernel size must be 1 or 3 (got %d)", k);
-    G2S_REQUIRE(mode == G2S_CONV_PLAIN || ((mode == G2S_CONV_UP2 || mode == G2S_CONV_DOWN2) && k == 3),
-                "unsupported mode %d with k=%d", mode, k);
+    G2S_REQUIRE(mode == G2S_CONV_PLAIN || mode == G2S_CONV_UP2 || mode == G2S_CONV_DOWN2,
+                "unsupported mode %d", mode);
     ConvDesc d{};
     d.x = x;
     d.w = w;
@@ -349,6 +349,7 @@ extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale
                     for (int kx = px; kx < k; kx += 2)
                         c.tab[c.T++] = pack((py - ky) / 2, (px - kx) / 2, ky * k + kx);
             }
+        if (k == 1) d.ncls = 1;  // only parity (0,0) receives data; the rest of y is zero-filled below
     }
     // tile configuration + split-K: aim for >= 2 workgroups (8 waves) per CU
     long nmax = 0;
@@ -371,7 +372,7 @@ extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale
     int splitk = 1;
     while ((long)tiles * d.ncls * splitk < 512 && kt_min / (splitk * 2) >= 8 && splitk < 64) splitk *= 2;
     d.splitk = splitk;
-    if (splitk > 1) {
+    if (splitk > 1 || (scatter && k == 1)) {
         if (hipMemsetAsync(y, 0, (size_t)B * d.M * d.OHf * d.OWf * sizeof(float), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
     }

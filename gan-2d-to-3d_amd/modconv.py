@@ -178,3 +178,42 @@ def _weight_grad(x, w, s, demod, gy, mode):
 def modconv(x, w, s=None, demod=None, mode=PLAIN):
     """x [B,Cin,H,W]; w [Cout,Cin,k,k] (scaled); s [B,Cin] or None; demod [B,Cout] or None."""
     return ModConvFunction.apply(x, w, s, demod, mode)
+
+
+class PlainConvFunction(Function):
+    """Un-modulated convolution on the same MFMA kernel (in_scale = out_scale = NULL): the
+    discriminator's EqualConv2d layers (stylegan2-pytorch/model.py:94-123,630-697) — 3x3 / 1x1,
+    stride 1 with padding k//2, or stride 2 without padding.  Data-gradient on the GPU kernel;
+    weight-gradient (never needed for the frozen D) through torch."""
+
+    @staticmethod
+    def forward(ctx, x, w, mode):
+        ctx.mode = mode
+        ctx.save_for_backward(x if ctx.needs_input_grad[1] else None, w)
+        return modconv_raw(x, w, None, None, mode, 0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = modconv_raw(gy.contiguous(), w, None, None, ctx.mode, 1)
+        if ctx.needs_input_grad[1]:
+            gw = _weight_grad(x, w, None, None, gy, ctx.mode)
+        return gx, gw, None
+
+
+def conv2d_supported(x, w, stride, padding):
+    k = w.shape[2]
+    if not (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and w.shape[2] == w.shape[3]
+            and k in (1, 3)):
+        return None
+    if stride == 1 and padding == k // 2:
+        return PLAIN
+    if stride == 2 and padding == 0 and (x.shape[2] - k) % 2 == 0 and (x.shape[3] - k) % 2 == 0:
+        return DOWN2
+    return None
+
+
+def conv2d(x, w, mode):
+    return PlainConvFunction.apply(x, w, mode)

@@ -132,7 +132,7 @@ int g2s_upfirdn2d(const void *x, const float *k, void *y, int major, int in_h, i
  *   G2S_CONV_UP2   : y[b,i,Y,X]            = sum x[b,o,2Y+ky,2X+kx] w[o,i,ky,kx] (adjoint of UP2;
  *                    here H, W are the sizes of x and must be odd: out (H-k)/2+1)
  * x [B, C_in_of_this_call, H, W] f32; in_scale [B, C_in_of_this_call] or NULL;
- * out_scale [B, C_out_of_this_call] or NULL; y fully overwritten.  k in {1, 3} (1 only PLAIN).
+ * out_scale [B, C_out_of_this_call] or NULL; y fully overwritten.  k in {1, 3}.
  * ---------------------------------------------------------------------------------------- */
 #define G2S_CONV_PLAIN 0
 #define G2S_CONV_UP2 1

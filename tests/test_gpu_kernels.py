@@ -311,3 +311,24 @@ def test_demodulation_matches_torch(g2s):
         (gs,) = torch.autograd.grad(d, s, g)
         (gref,) = torch.autograd.grad(ref, s, g)
         torch.testing.assert_close(gs, gref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,cin,cout,h,k,stride", [
+    (2, 16, 24, 20, 3, 1), (2, 32, 48, 35, 3, 2), (2, 24, 40, 17, 1, 2), (8, 3, 128, 16, 1, 1),
+    (1, 130, 70, 9, 3, 2)])
+def test_plain_conv_matches_torch(g2s, B, cin, cout, h, k, stride):
+    """EqualConv2d path of the discriminator: forward and data-gradient vs torch's conv."""
+    from gan2shape_amd.modconv import conv2d, conv2d_supported
+    torch.manual_seed(0)
+    x = torch.randn(B, cin, h, h, device="cuda", requires_grad=True)
+    w = torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5
+    pad = k // 2 if stride == 1 else 0
+    mode = conv2d_supported(x, w, stride, pad)
+    assert mode is not None
+    y = conv2d(x, w, mode)
+    ref = torch.nn.functional.conv2d(x, w, stride=stride, padding=pad)
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=2e-5)
+    g = torch.randn_like(ref)
+    (gx,) = torch.autograd.grad(y, x, g)
+    (gref,) = torch.autograd.grad(ref, x, g)
+    torch.testing.assert_close(gx, gref, rtol=1e-4, atol=2e-5)
