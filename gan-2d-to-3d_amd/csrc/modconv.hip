@@ -57,13 +57,19 @@ struct ConvDesc {
 constexpr int BK_MAX = 18;
 template <int T> struct KTile { static constexpr int BKT = (T == 9) ? 18 : 16; static constexpr int CPT = BKT / T; };
 
-template <int BM, int BN, int T>
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+
+// PARTIAL: the last K tile may run past the last reduction channel (Cr % channels-per-tile != 0);
+// SCALE: an input scale (style / demod) multiplies the im2col operand on its way into LDS.
+template <int BM, int BN, int T, bool PARTIAL, bool SCALE>
 __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass &c,
                                              float (&As)[2][BK_MAX][BM + 1],
                                              float (&Bs)[2][BK_MAX + 1][BN], const int (&stab)[9]) {
     constexpr int BKT = KTile<T>::BKT, CPT = KTile<T>::CPT;
     constexpr int WMT = BM / 64, WNT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
-    constexpr int EA = (BM * BKT + NTHREADS - 1) / NTHREADS, EB = (BN * BKT + NTHREADS - 1) / NTHREADS;
+    constexpr bool WIDE = (T == 9);              // 9 contiguous taps per (m, channel): 3 x dwordx3
+    constexpr int EA = WIDE ? (BM * 6 + NTHREADS - 1) / NTHREADS : (BM * BKT + NTHREADS - 1) / NTHREADS;
+    constexpr int EB = (BN * BKT + NTHREADS - 1) / NTHREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int Ncls = d.B * c.OH * c.OW;
@@ -82,9 +88,8 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
     // hardware range check zeroes masked elements, so the K loop carries no address arithmetic.
     const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, d.B * d.Cr * HW * 4, 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)d.w, 0, d.w_bytes, 0x00020000);
-    const bool has_scale = d.in_scale != nullptr;
     const auto rsc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(has_scale ? d.in_scale : d.w), 0, has_scale ? d.B * d.Cr * 4 : 4, 0x00020000);
+        (void *)(SCALE ? d.in_scale : d.w), 0, SCALE ? d.B * d.Cr * 4 : 4, 0x00020000);
 
     // ---- im2col elements of this thread: column n fixed, rows k_e = tid / BN + e * (256 / BN)
     const int nB = tid % BN;
@@ -97,7 +102,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
         iy0 = (r / c.OW) * d.is;
         ix0 = (r % c.OW) * d.is;
     }
-    int offB[EB], offS[EB], dchB[EB];
+    int offB[EB], dchB[EB];
 #pragma unroll
     for (int e = 0; e < EB; e++) {
         const int k = tid / BN + e * (NTHREADS / BN);
@@ -106,46 +111,81 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
         const int iy = iy0 + (tb & 0xff) - 8, ix = ix0 + ((tb >> 8) & 0xff) - 8;
         const bool ok = n_ok && k < BKT && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
         offB[e] = ok ? (((bb * d.Cr + dch) * d.H + iy) * d.W + ix) * 4 : OOB;
-        offS[e] = ok ? (bb * d.Cr + dch) * 4 : OOB;
         dchB[e] = dch;
     }
-    // ---- weight elements: idx = tid + e * 256 -> k = idx % BKT (lanes along contiguous taps)
+    const int offS = n_ok ? bb * d.Cr * 4 : OOB;  // + channel * 4
+    // ---- weight elements.  WIDE: idx -> (m, channel-in-tile, tap triple): one dwordx3 each;
+    //      else idx -> k = idx % BKT (lanes along contiguous taps), one dword each.
     int offA[EA], ldsA[EA], dchA[EA];
 #pragma unroll
     for (int e = 0; e < EA; e++) {
         const int idx = tid + e * NTHREADS;
-        const int k = idx % BKT, m = idx / BKT;
-        const int dch = k / T, t = k - dch * T;
-        const bool ok = idx < BM * BKT && m0 + m < d.M;
-        offA[e] = ok ? ((m0 + m) * d.w_ms + dch * d.w_ks + (stab[t] >> 16)) * 4 : OOB;
-        ldsA[e] = (idx < BM * BKT) ? k * (BM + 1) + m : BM;  // surplus elements land in the row padding
-        dchA[e] = dch;
+        if (WIDE) {
+            const int m = idx / 6, r = idx % 6, dch = r / 3, tg = r % 3;
+            const bool in = idx < BM * 6, ok = in && m0 + m < d.M;
+            offA[e] = ok ? ((m0 + m) * d.w_ms + dch * d.w_ks + 3 * tg) * 4 : OOB;
+            ldsA[e] = in ? (dch * 9 + 3 * tg) * (BM + 1) + m : BM;  // surplus: the pad column of rows 0..2
+            dchA[e] = dch;
+        } else {
+            const int k = idx % BKT, m = idx / BKT;
+            const int dch = k / T, t = k - dch * T;
+            const bool ok = idx < BM * BKT && m0 + m < d.M;
+            offA[e] = ok ? ((m0 + m) * d.w_ms + dch * d.w_ks + (stab[t] >> 16)) * 4 : OOB;
+            ldsA[e] = (idx < BM * BKT) ? k * (BM + 1) + m : BM;  // surplus lands in the row padding
+            dchA[e] = dch;
+        }
     }
-    const bool partial = (d.Cr % CPT) != 0;  // only then can a tile run past the last channel
 
     // Software pipeline, one barrier per K tile:
     //   registers hold tile t+1 (loads issued one iteration earlier), LDS buffer t&1 is being
     //   multiplied, buffer (t+1)&1 is free.  Inside the MFMA sequence of tile t, after each k-step,
-    //   one A element and one B element of tile t+1 are written to the free buffer and their
-    //   registers are immediately re-loaded with tile t+2 — the staging LDS / VMEM work issues in
-    //   the shadow of the 64-cycle MFMAs instead of in a phase of its own.
-    float ra[EA], rb[EB], rs[EB];
+    //   a slice of tile t+1 is written to the free buffer and its registers are immediately
+    //   re-loaded with tile t+2 — the staging LDS / VMEM work issues in the shadow of the 64-cycle
+    //   MFMAs instead of in a phase of its own.
+    float ra[EA][WIDE ? 3 : 1], rb[EB];
+    float rs[WIDE ? 2 : EB], rsn[2];  // WIDE: the tile's two channel scales (current / next tile)
     auto loadA = [&](int e, int kt) {
         const int ch0 = kt * CPT;
-        const int vo = (partial && dchA[e] >= d.Cr - ch0) ? OOB : offA[e];
-        ra[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, vo, ch0 * d.w_ks * 4, 0));
+        const int vo = (PARTIAL && dchA[e] >= d.Cr - ch0) ? OOB : offA[e];
+        if constexpr (WIDE) {
+            const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rw, vo, ch0 * d.w_ks * 4, 0);
+            ra[e][0] = __uint_as_float(v.x);
+            ra[e][1] = __uint_as_float(v.y);
+            ra[e][2] = __uint_as_float(v.z);
+        } else {
+            ra[e][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, vo, ch0 * d.w_ks * 4, 0));
+        }
     };
     auto loadB = [&](int e, int kt) {
         const int ch0 = kt * CPT;
-        const bool out = partial && dchB[e] >= d.Cr - ch0;
+        const bool out = PARTIAL && dchB[e] >= d.Cr - ch0;
         rb[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, out ? OOB : offB[e], ch0 * HW * 4, 0));
-        if (has_scale)
-            rs[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, out ? OOB : offS[e], ch0 * 4, 0));
+        if constexpr (SCALE && !WIDE)
+            rs[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                rsc, out ? OOB : offS + dchB[e] * 4, ch0 * 4, 0));
     };
-    auto storeA = [&](int e, float *abuf) { abuf[ldsA[e]] = ra[e]; };
+    auto loadS = [&](int kt, float (&dst)[2]) {  // WIDE only: scales of the tile's two channels
+        if constexpr (SCALE && WIDE) {
+            const int ch0 = kt * CPT;
+            dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, offS, ch0 * 4, 0));
+            dst[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                rsc, (PARTIAL && 1 >= d.Cr - ch0) ? OOB : offS + 4, ch0 * 4, 0));
+        }
+    };
+    auto storeA = [&](int e, float *abuf) {
+        if constexpr (WIDE) {
+            abuf[ldsA[e]] = ra[e][0];
+            abuf[ldsA[e] + (BM + 1)] = ra[e][1];
+            abuf[ldsA[e] + 2 * (BM + 1)] = ra[e][2];
+        } else {
+            abuf[ldsA[e]] = ra[e][0];
+        }
+    };
     auto storeB = [&](int e, float (*bbuf)[BN]) {
         const int k = tid / BN + e * (NTHREADS / BN);
-        bbuf[k < BKT ? k : BK_MAX][nB] = has_scale ? rb[e] * rs[e] : rb[e];  // row BK_MAX = dump row
+        float v = rb[e];
+        if constexpr (SCALE) v *= WIDE ? (dchB[e] ? rs[1] : rs[0]) : rs[e];
+        bbuf[k < BKT ? k : BK_MAX][nB] = v;  // row BK_MAX = dump row
     };
 
     f32x16 acc[WMT][WNT];
@@ -162,10 +202,12 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
     for (int e = 0; e < EA; e++) loadA(e, kt_begin);
 #pragma unroll
     for (int e = 0; e < EB; e++) loadB(e, kt_begin);
+    if constexpr (WIDE) loadS(kt_begin, rs);
 #pragma unroll
     for (int e = 0; e < EA; e++) { storeA(e, &As[0][0][0]); loadA(e, min(kt_begin + 1, kt_last)); }
 #pragma unroll
     for (int e = 0; e < EB; e++) { storeB(e, Bs[0]); loadB(e, min(kt_begin + 1, kt_last)); }
+    if constexpr (WIDE) loadS(min(kt_begin + 1, kt_last), rs);
     __syncthreads();
     const int l31 = lane & 31, lk = lane >> 5;
 
@@ -192,6 +234,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
 #pragma unroll
                 for (int j = 0; j < WNT; j++) b[p ^ 1][j] = Bs[cur][k2n + lk][wn * (BN / 2) + j * 32 + l31];
             }
+            if (WIDE && st == 0) loadS(kt2, rsn);  // scales of tile kt+2, used from the next iteration on
             int slot = 0;
 #pragma unroll
             for (int i = 0; i < WMT; i++)
@@ -214,6 +257,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
             }
         }
+        if constexpr (WIDE && SCALE) { rs[0] = rsn[0]; rs[1] = rsn[1]; }
         __syncthreads();
     };
     int kt = kt_begin;
@@ -267,11 +311,29 @@ __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
     if ((int)blockIdx.y * per >= ktiles) return;
     if (threadIdx.x < 9) stab[threadIdx.x] = c.tab[threadIdx.x];
     __syncthreads();
-    switch (c.T) {  // compile-time tap count
-    case 9: modconv_body<BM, BN, 9>(d, c, As, Bs, stab); break;
-    case 4: modconv_body<BM, BN, 4>(d, c, As, Bs, stab); break;
-    case 2: modconv_body<BM, BN, 2>(d, c, As, Bs, stab); break;
-    default: modconv_body<BM, BN, 1>(d, c, As, Bs, stab); break;
+    const bool scale = d.in_scale != nullptr;
+    switch (c.T) {  // compile-time tap count (and, for the hot 3x3 case, no partial-tile checks)
+    case 9:
+        if (d.Cr % 2) {
+            if (scale) modconv_body<BM, BN, 9, true, true>(d, c, As, Bs, stab);
+            else modconv_body<BM, BN, 9, true, false>(d, c, As, Bs, stab);
+        } else {
+            if (scale) modconv_body<BM, BN, 9, false, true>(d, c, As, Bs, stab);
+            else modconv_body<BM, BN, 9, false, false>(d, c, As, Bs, stab);
+        }
+        break;
+    case 4:
+        if (scale) modconv_body<BM, BN, 4, true, true>(d, c, As, Bs, stab);
+        else modconv_body<BM, BN, 4, true, false>(d, c, As, Bs, stab);
+        break;
+    case 2:
+        if (scale) modconv_body<BM, BN, 2, true, true>(d, c, As, Bs, stab);
+        else modconv_body<BM, BN, 2, true, false>(d, c, As, Bs, stab);
+        break;
+    default:
+        if (scale) modconv_body<BM, BN, 1, true, true>(d, c, As, Bs, stab);
+        else modconv_body<BM, BN, 1, true, false>(d, c, As, Bs, stab);
+        break;
     }
 }
 
