@@ -1,0 +1,323 @@
+// geometry.hip — fused renderer geometry / loss glue of the GAN2Shape step (HBM-bound elementwise
+// chains that the reference runs as dozens of tiny launches each, forward and again in autograd).
+//
+//   g2s_view_transform_*   model.py:330-335 get_view_transformation + renderer/utils.py:33-73
+//                          (view[B,6] -> R = Rz Ry Rx [B,3,3], t [B,3])
+//   g2s_warp_verts_*       renderer.py:74-80,64-72,90-95  depth -> d*ray -> R(X - c) + c + t
+//   g2s_inv_warp_grid_*    renderer.py:97-102,82-88,110-114  depth -> R^T(d*ray - t - c) + c -> K -> [-1,1]
+//   g2s_smooth_loss_*      losses.py:54-79  second-order smoothness of a [N,H,W] map
+//
+// Every backward is analytic; per-batch reductions (gradients of R and t) are reduced in the
+// workgroup and added with one float atomic per workgroup and component.
+#include "g2s_common.h"
+
+namespace g2s {
+
+__device__ __forceinline__ float wave_sum_g(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Sum `v` over the 256 threads of the workgroup and atomically add it to *dst (thread 0).
+__device__ __forceinline__ void block_atomic_add(float v, float *dst, float *red) {
+    v = wave_sum_g(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(dst, red[0] + red[1] + red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------ view -> (R, t)
+struct ViewScale { float rot, txy, tz; };  // pi/180*xyz_rotation_range, xy_translation_range, z_translation_range
+
+__global__ void view_transform_fwd(const float *__restrict__ view, ViewScale s, float *__restrict__ R,
+                                   float *__restrict__ t, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *v = view + b * 6;
+    const float ax = v[0] * s.rot, ay = v[1] * s.rot, az = v[2] * s.rot;
+    const float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay), cz = cosf(az), sz = sinf(az);
+    float *r = R + b * 9;
+    // Rz * Ry * Rx
+    r[0] = cz * cy;  r[1] = cz * sy * sx - sz * cx;  r[2] = cz * sy * cx + sz * sx;
+    r[3] = sz * cy;  r[4] = sz * sy * sx + cz * cx;  r[5] = sz * sy * cx - cz * sx;
+    r[6] = -sy;      r[7] = cy * sx;                 r[8] = cy * cx;
+    t[b * 3 + 0] = v[3] * s.txy;
+    t[b * 3 + 1] = v[4] * s.txy;
+    t[b * 3 + 2] = v[5] * s.tz;
+}
+
+__global__ void view_transform_bwd(const float *__restrict__ view, ViewScale s,
+                                   const float *__restrict__ gR, const float *__restrict__ gt,
+                                   float *__restrict__ gview, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *v = view + b * 6;
+    const float ax = v[0] * s.rot, ay = v[1] * s.rot, az = v[2] * s.rot;
+    const float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay), cz = cosf(az), sz = sinf(az);
+    const float *g = gR + b * 9;
+    // d/dax
+    const float dax = g[1] * (cz * sy * cx + sz * sx) + g[2] * (-cz * sy * sx + sz * cx) +
+                      g[4] * (sz * sy * cx - cz * sx) + g[5] * (-sz * sy * sx - cz * cx) +
+                      g[7] * (cy * cx) + g[8] * (-cy * sx);
+    const float day = g[0] * (-cz * sy) + g[1] * (cz * cy * sx) + g[2] * (cz * cy * cx) +
+                      g[3] * (-sz * sy) + g[4] * (sz * cy * sx) + g[5] * (sz * cy * cx) +
+                      g[6] * (-cy) + g[7] * (-sy * sx) + g[8] * (-sy * cx);
+    const float daz = g[0] * (-sz * cy) + g[1] * (-sz * sy * sx - cz * cx) + g[2] * (-sz * sy * cx + cz * sx) +
+                      g[3] * (cz * cy) + g[4] * (cz * sy * sx - sz * cx) + g[5] * (cz * sy * cx + sz * sx);
+    float *o = gview + b * 6;
+    o[0] = dax * s.rot;
+    o[1] = day * s.rot;
+    o[2] = daz * s.rot;
+    o[3] = gt[b * 3 + 0] * s.txy;
+    o[4] = gt[b * 3 + 1] * s.txy;
+    o[5] = gt[b * 3 + 2] * s.tz;
+}
+
+// ------------------------------------------------------------------ depth -> warped vertices
+// grid (ceil(P / 256), B)
+__global__ __launch_bounds__(256) void warp_verts_fwd(const float *__restrict__ depth,
+                                                      const float *__restrict__ rays,
+                                                      const float *__restrict__ R,
+                                                      const float *__restrict__ t, float rcd,
+                                                      float *__restrict__ verts, int P) {
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float *r = R + b * 9, *tt = t + b * 3;
+    const float d = depth[(size_t)b * P + p];
+    const float x = rays[3 * p] * d, y = rays[3 * p + 1] * d, z = rays[3 * p + 2] * d - rcd;
+    float *o = verts + ((size_t)b * P + p) * 3;
+    o[0] = (x * r[0] + y * r[1] + z * r[2]) + tt[0];
+    o[1] = (x * r[3] + y * r[4] + z * r[5]) + tt[1];
+    o[2] = ((x * r[6] + y * r[7] + z * r[8]) + rcd) + tt[2];
+}
+
+// gRt [B, 12] (9 of R row-major, then 3 of t) must be zero-filled by the caller.
+__global__ __launch_bounds__(256) void warp_verts_bwd(const float *__restrict__ depth,
+                                                      const float *__restrict__ rays,
+                                                      const float *__restrict__ R,
+                                                      const float *__restrict__ gverts, float rcd,
+                                                      float *__restrict__ gdepth,
+                                                      float *__restrict__ gRt, int P, int need_rt) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = p < P;
+    const float *r = R + b * 9;
+    float g0 = 0, g1 = 0, g2 = 0, x = 0, y = 0, z = 0;
+    if (ok) {
+        const float *g = gverts + ((size_t)b * P + p) * 3;
+        g0 = g[0]; g1 = g[1]; g2 = g[2];
+        const float d = depth[(size_t)b * P + p];
+        const float rx = rays[3 * p], ry = rays[3 * p + 1], rz = rays[3 * p + 2];
+        x = rx * d; y = ry * d; z = rz * d - rcd;
+        // gX = R^T g ; gd = gX . ray
+        const float gx = r[0] * g0 + r[3] * g1 + r[6] * g2;
+        const float gy = r[1] * g0 + r[4] * g1 + r[7] * g2;
+        const float gz = r[2] * g0 + r[5] * g1 + r[8] * g2;
+        gdepth[(size_t)b * P + p] = gx * rx + gy * ry + gz * rz;
+    }
+    if (!need_rt) return;
+    float *o = gRt + b * 12;
+    block_atomic_add(g0 * x, o + 0, red); block_atomic_add(g0 * y, o + 1, red); block_atomic_add(g0 * z, o + 2, red);
+    block_atomic_add(g1 * x, o + 3, red); block_atomic_add(g1 * y, o + 4, red); block_atomic_add(g1 * z, o + 5, red);
+    block_atomic_add(g2 * x, o + 6, red); block_atomic_add(g2 * y, o + 7, red); block_atomic_add(g2 * z, o + 8, red);
+    block_atomic_add(g0, o + 9, red); block_atomic_add(g1, o + 10, red); block_atomic_add(g2, o + 11, red);
+}
+
+// ------------------------------------------------------------------ depth -> inverse-warped 2-D grid
+struct Intr { float k00, k01, k02, k10, k11, k12, sx, sy; };  // sx = 2/(W-1), sy = 2/(H-1)
+
+__global__ __launch_bounds__(256) void inv_warp_grid_fwd(const float *__restrict__ depth,
+                                                         const float *__restrict__ rays,
+                                                         const float *__restrict__ R,
+                                                         const float *__restrict__ t, float rcd,
+                                                         Intr K, float *__restrict__ grid, int P) {
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float *r = R + b * 9, *tt = t + b * 3;
+    const float d = depth[(size_t)b * P + p];
+    const float zx = rays[3 * p] * d - tt[0], zy = rays[3 * p + 1] * d - tt[1],
+                zz = (rays[3 * p + 2] * d - tt[2]) - rcd;
+    // Y = R^T (Z - c) + c
+    const float yx = zx * r[0] + zy * r[3] + zz * r[6];
+    const float yy = zx * r[1] + zy * r[4] + zz * r[7];
+    const float yz = (zx * r[2] + zy * r[5] + zz * r[8]) + rcd;
+    const float a = yx / yz, bq = yy / yz;
+    const float u = (a * K.k00 + bq * K.k01) + K.k02, v = (a * K.k10 + bq * K.k11) + K.k12;
+    float *o = grid + ((size_t)b * P + p) * 2;
+    o[0] = u * K.sx - 1.0f;
+    o[1] = v * K.sy - 1.0f;
+}
+
+__global__ __launch_bounds__(256) void inv_warp_grid_bwd(const float *__restrict__ depth,
+                                                         const float *__restrict__ rays,
+                                                         const float *__restrict__ R,
+                                                         const float *__restrict__ t, float rcd,
+                                                         Intr K, const float *__restrict__ ggrid,
+                                                         float *__restrict__ gdepth,
+                                                         float *__restrict__ gRt, int P, int need_rt) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = p < P;
+    const float *r = R + b * 9, *tt = t + b * 3;
+    float zx = 0, zy = 0, zz = 0, gyx = 0, gyy = 0, gyz = 0, gzx = 0, gzy = 0, gzz = 0;
+    if (ok) {
+        const float d = depth[(size_t)b * P + p];
+        const float rx = rays[3 * p], ry = rays[3 * p + 1], rz = rays[3 * p + 2];
+        zx = rx * d - tt[0]; zy = ry * d - tt[1]; zz = (rz * d - tt[2]) - rcd;
+        const float yx = zx * r[0] + zy * r[3] + zz * r[6];
+        const float yy = zx * r[1] + zy * r[4] + zz * r[7];
+        const float yz = (zx * r[2] + zy * r[5] + zz * r[8]) + rcd;
+        const float *g = ggrid + ((size_t)b * P + p) * 2;
+        const float gu = g[0] * K.sx, gv = g[1] * K.sy;
+        const float ga = gu * K.k00 + gv * K.k10, gb = gu * K.k01 + gv * K.k11;
+        gyx = ga / yz; gyy = gb / yz; gyz = -(ga * yx + gb * yy) / (yz * yz);
+        // gZ = R gY
+        gzx = r[0] * gyx + r[1] * gyy + r[2] * gyz;
+        gzy = r[3] * gyx + r[4] * gyy + r[5] * gyz;
+        gzz = r[6] * gyx + r[7] * gyy + r[8] * gyz;
+        gdepth[(size_t)b * P + p] = gzx * rx + gzy * ry + gzz * rz;
+    }
+    if (!need_rt) return;
+    float *o = gRt + b * 12;
+    // Y_k = sum_j R_jk (Z - c)_j  =>  gR_jk = (Z - c)_j gY_k
+    block_atomic_add(zx * gyx, o + 0, red); block_atomic_add(zx * gyy, o + 1, red); block_atomic_add(zx * gyz, o + 2, red);
+    block_atomic_add(zy * gyx, o + 3, red); block_atomic_add(zy * gyy, o + 4, red); block_atomic_add(zy * gyz, o + 5, red);
+    block_atomic_add(zz * gyx, o + 6, red); block_atomic_add(zz * gyy, o + 7, red); block_atomic_add(zz * gyz, o + 8, red);
+    block_atomic_add(-gzx, o + 9, red); block_atomic_add(-gzy, o + 10, red); block_atomic_add(-gzz, o + 11, red);
+}
+
+// ------------------------------------------------------------------ smoothness loss
+// loss = mean|dx2| + mean|dxdy| + mean|dydx| + mean|dy2| over a [N, H, W] map (losses.py:54-79);
+// dxdy == dydx element-wise (mixed second difference).  grid (ceil(W/32), ceil(H/8), N), block (32, 8)
+__device__ __forceinline__ float sgn(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
+
+__global__ __launch_bounds__(256) void smooth_loss_fwd(const float *__restrict__ pm, float *__restrict__ loss,
+                                                       int H, int W, float w_xx, float w_xy, float w_yy) {
+    __shared__ float red[4];
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const float *p = pm + (size_t)blockIdx.z * H * W;
+    float acc = 0.0f;
+    if (x < W && y < H) {
+        const float c = p[y * W + x];
+        if (x + 2 < W) acc += w_xx * fabsf(p[y * W + x + 2] - 2.0f * p[y * W + x + 1] + c);
+        if (y + 2 < H) acc += w_yy * fabsf(p[(y + 2) * W + x] - 2.0f * p[(y + 1) * W + x] + c);
+        if (x + 1 < W && y + 1 < H)
+            acc += w_xy * fabsf((p[(y + 1) * W + x + 1] - p[(y + 1) * W + x]) - (p[y * W + x + 1] - c));
+    }
+    block_atomic_add(acc, loss, red);
+}
+
+__global__ __launch_bounds__(256) void smooth_loss_bwd(const float *__restrict__ pm,
+                                                       const float *__restrict__ gloss,
+                                                       float *__restrict__ gp, int H, int W,
+                                                       float w_xx, float w_xy, float w_yy) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    const float *p = pm + (size_t)blockIdx.z * H * W;
+    auto P = [&](int yy, int xx) { return p[yy * W + xx]; };
+    auto sxx = [&](int yy, int j) {  // sign of dx2 at (yy, j), j in [0, W-3]
+        return (j >= 0 && j + 2 < W) ? sgn(P(yy, j + 2) - 2.0f * P(yy, j + 1) + P(yy, j)) : 0.0f;
+    };
+    auto syy = [&](int i, int xx) {
+        return (i >= 0 && i + 2 < H) ? sgn(P(i + 2, xx) - 2.0f * P(i + 1, xx) + P(i, xx)) : 0.0f;
+    };
+    auto sxy = [&](int i, int j) {
+        return (i >= 0 && j >= 0 && i + 1 < H && j + 1 < W)
+                   ? sgn((P(i + 1, j + 1) - P(i + 1, j)) - (P(i, j + 1) - P(i, j))) : 0.0f;
+    };
+    float g = w_xx * (sxx(y, x - 2) - 2.0f * sxx(y, x - 1) + sxx(y, x));
+    g += w_yy * (syy(y - 2, x) - 2.0f * syy(y - 1, x) + syy(y, x));
+    g += w_xy * (sxy(y - 1, x - 1) - sxy(y - 1, x) - sxy(y, x - 1) + sxy(y, x));
+    gp[(size_t)blockIdx.z * H * W + y * W + x] = g * gloss[0];
+}
+
+static Intr make_intr(const float *K, int H, int W) {
+    return Intr{K[0], K[1], K[2], K[3], K[4], K[5], 2.0f / (float)(W - 1), 2.0f / (float)(H - 1)};
+}
+
+}  // namespace g2s
+
+using namespace g2s;
+
+extern "C" int g2s_view_transform_fwd(const float *view, float rot_scale, float txy_scale,
+                                      float tz_scale, float *R, float *t, int B, g2s_stream_t stream) {
+    G2S_REQUIRE(view && R && t && B > 0, "bad argument");
+    view_transform_fwd<<<cdiv(B, 64), 64, 0, as_stream(stream)>>>(view, ViewScale{rot_scale, txy_scale, tz_scale}, R, t, B);
+    return check_launch("g2s_view_transform_fwd");
+}
+
+extern "C" int g2s_view_transform_bwd(const float *view, float rot_scale, float txy_scale,
+                                      float tz_scale, const float *gR, const float *gt, float *gview,
+                                      int B, g2s_stream_t stream) {
+    G2S_REQUIRE(view && gR && gt && gview && B > 0, "bad argument");
+    view_transform_bwd<<<cdiv(B, 64), 64, 0, as_stream(stream)>>>(view, ViewScale{rot_scale, txy_scale, tz_scale}, gR, gt, gview, B);
+    return check_launch("g2s_view_transform_bwd");
+}
+
+extern "C" int g2s_warp_verts_fwd(const float *depth, const float *rays, const float *R, const float *t,
+                                  float rot_center_depth, float *verts, int B, int P,
+                                  g2s_stream_t stream) {
+    G2S_REQUIRE(depth && rays && R && t && verts && B > 0 && P > 0 && B <= 65535, "bad argument");
+    warp_verts_fwd<<<dim3(cdiv(P, 256), B), 256, 0, as_stream(stream)>>>(depth, rays, R, t, rot_center_depth, verts, P);
+    return check_launch("g2s_warp_verts_fwd");
+}
+
+extern "C" int g2s_warp_verts_bwd(const float *depth, const float *rays, const float *R,
+                                  const float *gverts, float rot_center_depth, float *gdepth,
+                                  float *gRt, int B, int P, g2s_stream_t stream) {
+    G2S_REQUIRE(depth && rays && R && gverts && gdepth && B > 0 && P > 0 && B <= 65535, "bad argument");
+    hipStream_t st = as_stream(stream);
+    if (gRt && hipMemsetAsync(gRt, 0, (size_t)B * 12 * sizeof(float), st) != hipSuccess)
+        return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
+    warp_verts_bwd<<<dim3(cdiv(P, 256), B), 256, 0, st>>>(depth, rays, R, gverts, rot_center_depth, gdepth, gRt, P, gRt != nullptr);
+    return check_launch("g2s_warp_verts_bwd");
+}
+
+extern "C" int g2s_inv_warp_grid_fwd(const float *depth, const float *rays, const float *R,
+                                     const float *t, const float *K, float rot_center_depth,
+                                     float *grid, int B, int H, int W, g2s_stream_t stream) {
+    G2S_REQUIRE(depth && rays && R && t && K && grid && B > 0 && H > 1 && W > 1 && B <= 65535, "bad argument");
+    inv_warp_grid_fwd<<<dim3(cdiv(H * W, 256), B), 256, 0, as_stream(stream)>>>(
+        depth, rays, R, t, rot_center_depth, make_intr(K, H, W), grid, H * W);
+    return check_launch("g2s_inv_warp_grid_fwd");
+}
+
+extern "C" int g2s_inv_warp_grid_bwd(const float *depth, const float *rays, const float *R,
+                                     const float *t, const float *K, float rot_center_depth,
+                                     const float *ggrid, float *gdepth, float *gRt, int B, int H,
+                                     int W, g2s_stream_t stream) {
+    G2S_REQUIRE(depth && rays && R && t && K && ggrid && gdepth && B > 0 && H > 1 && W > 1 && B <= 65535, "bad argument");
+    hipStream_t st = as_stream(stream);
+    if (gRt && hipMemsetAsync(gRt, 0, (size_t)B * 12 * sizeof(float), st) != hipSuccess)
+        return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
+    inv_warp_grid_bwd<<<dim3(cdiv(H * W, 256), B), 256, 0, st>>>(
+        depth, rays, R, t, rot_center_depth, make_intr(K, H, W), ggrid, gdepth, gRt, H * W, gRt != nullptr);
+    return check_launch("g2s_inv_warp_grid_bwd");
+}
+
+static void smooth_weights(int N, int H, int W, float &wxx, float &wxy, float &wyy) {
+    wxx = (W > 2) ? 1.0f / ((float)N * H * (W - 2)) : 0.0f;
+    wyy = (H > 2) ? 1.0f / ((float)N * (H - 2) * W) : 0.0f;
+    wxy = (H > 1 && W > 1) ? 2.0f / ((float)N * (H - 1) * (W - 1)) : 0.0f;  // dxdy and dydx
+}
+
+extern "C" int g2s_smooth_loss_fwd(const float *p, float *loss, int N, int H, int W, g2s_stream_t stream) {
+    G2S_REQUIRE(p && loss && N > 0 && H > 0 && W > 0 && N <= 65535, "bad argument");
+    float wxx, wxy, wyy;
+    smooth_weights(N, H, W, wxx, wxy, wyy);
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
+    smooth_loss_fwd<<<dim3(cdiv(W, 32), cdiv(H, 8), N), 256, 0, st>>>(p, loss, H, W, wxx, wxy, wyy);
+    return check_launch("g2s_smooth_loss_fwd");
+}
+
+extern "C" int g2s_smooth_loss_bwd(const float *p, const float *gloss, float *gp, int N, int H, int W,
+                                   g2s_stream_t stream) {
+    G2S_REQUIRE(p && gloss && gp && N > 0 && H > 0 && W > 0 && N <= 65535, "bad argument");
+    float wxx, wxy, wyy;
+    smooth_weights(N, H, W, wxx, wxy, wyy);
+    smooth_loss_bwd<<<dim3(cdiv(W, 32), cdiv(H, 8), N), 256, 0, as_stream(stream)>>>(p, gloss, gp, H, W, wxx, wxy, wyy);
+    return check_launch("g2s_smooth_loss_bwd");
+}

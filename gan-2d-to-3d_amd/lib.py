@@ -30,6 +30,14 @@ SIGNATURES = {
     "g2s_demod_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_lpips_layer_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_lpips_layer_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "g2s_view_transform_fwd": (_i, [_p, _f, _f, _f, _p, _p, _i, _p]),
+    "g2s_view_transform_bwd": (_i, [_p, _f, _f, _f, _p, _p, _p, _i, _p]),
+    "g2s_warp_verts_fwd": (_i, [_p, _p, _p, _p, _f, _p, _i, _i, _p]),
+    "g2s_warp_verts_bwd": (_i, [_p, _p, _p, _p, _f, _p, _p, _i, _i, _p]),
+    "g2s_inv_warp_grid_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _p]),
+    "g2s_inv_warp_grid_bwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p]),
+    "g2s_smooth_loss_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
+    "g2s_smooth_loss_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
 }
 
 

@@ -52,6 +52,10 @@ class SmoothLoss():
     """Second-order smoothness (losses.py:54-79)."""
 
     def __call__(self, pred_map):
+        if torch.is_tensor(pred_map) and pred_map.is_cuda and pred_map.dtype == torch.float32 \
+                and pred_map.dim() in (3, 4):
+            from .fused_geometry import smooth_loss  # one kernel forward, one backward
+            return smooth_loss(pred_map)
         if type(pred_map) not in [tuple, list]:
             pred_map = [pred_map]
         loss = 0

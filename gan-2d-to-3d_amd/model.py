@@ -126,6 +126,11 @@ class GAN2Shape(nn.Module):
                           view[:, 3:5] * self.xy_translation_range,
                           view[:, 5:] * self.z_translation_range], 1)
 
+    def _set_view(self, view):
+        """renderer.set_transform_matrices(get_view_transformation(view)) (model.py:119-120)."""
+        self.renderer.set_view(view, math.pi / 180 * self.xyz_rotation_range,
+                               self.xy_translation_range, self.z_translation_range)
+
     def get_clamped_depth(self, depth_raw, h, w, clamp_border=True):
         """model.py:337-345: centre over the WHOLE batch, tanh, rescale; the two left/right border
         columns blend towards border_depth with weight 1.02."""
@@ -165,7 +170,7 @@ class GAN2Shape(nn.Module):
         with self._no_grad_if(step1):
             view = self.viewpoint_net(images)
         view = view + self.view_light_sampler.view_mean.unsqueeze(0)
-        self.renderer.set_transform_matrices(self.get_view_transformation(view))
+        self._set_view(view)
 
         albedo = self.albedo_net(images)
         with self._no_grad_if(step1):
@@ -287,7 +292,7 @@ class GAN2Shape(nn.Module):
 
         b = len(projected_samples)
         view = self.viewpoint_net(projected_samples) + self.view_light_sampler.view_mean.unsqueeze(0)
-        self.renderer.set_transform_matrices(self.get_view_transformation(view))
+        self._set_view(view)
         light = self.lighting_net(projected_samples) + self.view_light_sampler.light_mean.unsqueeze(0)
         light_a, light_b, light_d = self.get_lighting_directions(light)
         diffuse_shading, texture = self.get_shading(normal, light_a, light_b, light_d, albedo)

@@ -13,6 +13,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .. import fused_geometry as fg
 from ..plugins import neural_renderer as nr
 from .utils import get_face_idx, get_grid, get_transform_matrices
 
@@ -54,6 +55,14 @@ class Renderer():
                                     background_color=[1, 1, 1])
         self._centroid = torch.tensor([0., 0., self.rot_center_depth], device=self.device).view(1, 1, 3)
         self._rays = {}
+        self._K9 = (fx, 0., cx, 0., fy, cy, 0., 0., 1.)  # host copy of K for the fused kernels
+        # fused = True: on CUDA tensors the geometry chains below run as single libg2s kernels
+        # (csrc/geometry.hip); the torch code in each method is the specification they are tested
+        # against and the path for CPU tensors.
+        self.fused = True
+
+    def _use_fused(self, t):
+        return self.fused and t.is_cuda and t.dtype == torch.float32
 
     def _const(self, key, make):
         """Device constants are built once: a host->device copy inside the hot loop would also make
@@ -64,7 +73,19 @@ class Renderer():
         return v
 
     def set_transform_matrices(self, view):
-        self.rot_mat, self.trans_xyz = get_transform_matrices(view)
+        if self._use_fused(view) and view.size(1) == 6:
+            self.rot_mat, self.trans_xyz = fg.view_transform(view)
+        else:
+            self.rot_mat, self.trans_xyz = get_transform_matrices(view)
+
+    def set_view(self, view, rot_scale, txy_scale, tz_scale):
+        """set_transform_matrices(get_view_transformation(view)) of GAN2Shape/model.py:119-120,330-335
+        in one step: angles = view[:, :3] * rot_scale, t = (view[:, 3:5] * txy, view[:, 5] * tz)."""
+        if self._use_fused(view):
+            self.rot_mat, self.trans_xyz = fg.view_transform(view, rot_scale, txy_scale, tz_scale)
+        else:
+            self.set_transform_matrices(torch.cat([view[:, :3] * rot_scale, view[:, 3:5] * txy_scale,
+                                                   view[:, 5:] * tz_scale], 1))
 
     def rotate_pts(self, pts, rot_mat):
         centroid = self._centroid.to(pts.device)
@@ -100,6 +121,10 @@ class Renderer():
 
     def get_warped_3d_grid(self, depth):
         b, h, w = depth.shape
+        if self._use_fused(depth):
+            rays = self._pixel_rays(h, w, depth.device).reshape(-1, 3)
+            return fg.warp_verts(depth, rays, self.rot_mat, self.trans_xyz,
+                                 self.rot_center_depth).reshape(b, h, w, 3)
         grid_3d = self.depth_to_3d_grid(depth).reshape(b, -1, 3)
         grid_3d = self.rotate_pts(grid_3d, self.rot_mat)
         grid_3d = self.translate_pts(grid_3d, self.trans_xyz)
@@ -116,6 +141,11 @@ class Renderer():
         return self.grid_3d_to_2d(self.get_warped_3d_grid(depth))
 
     def get_inv_warped_2d_grid(self, depth):
+        if self._use_fused(depth):
+            b, h, w = depth.shape
+            rays = self._pixel_rays(h, w, depth.device).reshape(-1, 3)
+            return fg.inv_warp_grid(depth, rays, self.rot_mat, self.trans_xyz, self._K9,
+                                    self.rot_center_depth)
         return self.grid_3d_to_2d(self.get_inv_warped_3d_grid(depth))
 
     def warp_canon_depth(self, canon_depth):

@@ -169,6 +169,36 @@ int g2s_lpips_layer_fwd(const float *f0, const float *f1, const float *w, float 
 int g2s_lpips_layer_bwd(const float *f0, const float *f1, const float *w, const float *gout,
                         float *g0, int N, int C, int HW, g2s_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused renderer geometry / loss glue (csrc/geometry.hip).  All f32, device pointers; K is a HOST
+ * pointer to 9 floats.  rays [H*W, 3] = K^-1 (u, v, 1)^T per pixel (renderer.py:74-80); R [B,3,3],
+ * t [B,3]; rot_center_depth = z of the rotation centre (renderer.py:64-69).
+ *   g2s_view_transform_*  view [B,6] -> R = Rz Ry Rx, t  (model.py:330-335 + renderer/utils.py:33-73)
+ *   g2s_warp_verts_*      verts [B,H*W,3] = R (d ray - c) + c + t          (renderer.py:90-95)
+ *   g2s_inv_warp_grid_*   grid [B,H,W,2] = normalise(K (R^T (d ray - t - c) + c))  (renderer.py:97-114)
+ *   g2s_smooth_loss_*     mean|dx2| + mean|dxdy| + mean|dydx| + mean|dy2| of p [N,H,W]  (losses.py:54-79)
+ * Backward entry points write gdepth / gview / gp fully; gRt [B,12] (9 of R, 3 of t; may be NULL)
+ * is zero-filled by the callee then accumulated with one float atomic per workgroup.
+ * ---------------------------------------------------------------------------------------- */
+int g2s_view_transform_fwd(const float *view, float rot_scale, float txy_scale, float tz_scale,
+                           float *R, float *t, int B, g2s_stream_t stream);
+int g2s_view_transform_bwd(const float *view, float rot_scale, float txy_scale, float tz_scale,
+                           const float *gR, const float *gt, float *gview, int B, g2s_stream_t stream);
+int g2s_warp_verts_fwd(const float *depth, const float *rays, const float *R, const float *t,
+                       float rot_center_depth, float *verts, int B, int P, g2s_stream_t stream);
+int g2s_warp_verts_bwd(const float *depth, const float *rays, const float *R, const float *gverts,
+                       float rot_center_depth, float *gdepth, float *gRt, int B, int P,
+                       g2s_stream_t stream);
+int g2s_inv_warp_grid_fwd(const float *depth, const float *rays, const float *R, const float *t,
+                          const float *K, float rot_center_depth, float *grid, int B, int H, int W,
+                          g2s_stream_t stream);
+int g2s_inv_warp_grid_bwd(const float *depth, const float *rays, const float *R, const float *t,
+                          const float *K, float rot_center_depth, const float *ggrid, float *gdepth,
+                          float *gRt, int B, int H, int W, g2s_stream_t stream);
+int g2s_smooth_loss_fwd(const float *p, float *loss, int N, int H, int W, g2s_stream_t stream);
+int g2s_smooth_loss_bwd(const float *p, const float *gloss, float *gp, int N, int H, int W,
+                        g2s_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -237,3 +237,55 @@ def test_lpips_fused_tail_matches_reference_form():
         assert fused.shape == ref.shape == (B, 1, 1, 1)
         torch.testing.assert_close(fused, ref, rtol=2e-5, atol=1e-7)
         torch.testing.assert_close(g_fused, g_ref, rtol=2e-4, atol=2e-6 * float(g_ref.abs().max()) + 1e-9)
+
+
+def test_fused_geometry_matches_torch_path():
+    """csrc/geometry.hip kernels vs the torch restatement of renderer.py / losses.py they replace
+    (values and gradients w.r.t. depth and view)."""
+    import gan2shape_amd  # noqa: F401
+    from gan2shape_amd.losses import SmoothLoss
+    from gan2shape_amd.renderer import Renderer
+    torch.manual_seed(0)
+    S, B = 64, 3
+    R = Renderer({"rot_center_depth": 1.0, "fov": 10}, S, 0.9, 1.1, device="cuda")
+    depth0 = (0.9 + 0.2 * torch.rand(B, S, S, device="cuda"))
+    view0 = torch.randn(B, 6, device="cuda") * 0.3
+    scales = (math.pi / 180 * 60, 0.1, 0.1)
+    outs = {}
+    for fused in (True, False):
+        R.fused = fused
+        depth = depth0.clone().requires_grad_(True)
+        view = view0.clone().requires_grad_(True)
+        R.set_view(view, *scales)
+        rot, trans = R.rot_mat, R.trans_xyz
+        verts = R.get_warped_3d_grid(depth)
+        grid = R.get_inv_warped_2d_grid(depth)
+        sm = SmoothLoss()(depth) if fused else _smooth_ref(depth)
+        gen = torch.Generator(device="cuda").manual_seed(1)
+        wv = torch.randn(verts.shape, device="cuda", generator=gen)
+        wg = torch.randn(grid.shape, device="cuda", generator=gen)
+        loss = (verts * wv).sum() + (grid * wg).sum() * 0.01 + 3.0 * sm
+        gd, gvw = torch.autograd.grad(loss, (depth, view))
+        outs[fused] = dict(rot=rot, trans=trans, verts=verts, grid=grid, sm=sm, gd=gd, gv=gvw)
+    a, b = outs[True], outs[False]
+    for k in ("rot", "trans", "verts"):
+        torch.testing.assert_close(a[k], b[k], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a["grid"], b["grid"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(a["sm"], b["sm"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(a["gd"], b["gd"], rtol=1e-3, atol=1e-4 * float(b["gd"].abs().max()))
+    torch.testing.assert_close(a["gv"], b["gv"], rtol=1e-3, atol=1e-4 * float(b["gv"].abs().max()))
+    # 4-D map (diffuse shading) through the fused smoothness loss
+    x = torch.rand(2, 1, 20, 33, device="cuda", requires_grad=True)
+    l1, l2 = SmoothLoss()(x), _smooth_ref(x)
+    torch.testing.assert_close(l1, l2, rtol=1e-5, atol=1e-7)
+    (g1,), (g2,) = torch.autograd.grad(l1, x), torch.autograd.grad(l2, x)
+    torch.testing.assert_close(g1, g2, rtol=1e-5, atol=1e-8)
+
+
+def _smooth_ref(pred):
+    """losses.py:54-79 in plain torch ops."""
+    p = pred.reshape(-1, pred.size(-2), pred.size(-1))
+    dx, dy = p[:, :, 1:] - p[:, :, :-1], p[:, 1:] - p[:, :-1]
+    dx2, dxdy = dx[:, :, 1:] - dx[:, :, :-1], dx[:, 1:] - dx[:, :-1]
+    dydx, dy2 = dy[:, :, 1:] - dy[:, :, :-1], dy[:, 1:] - dy[:, :-1]
+    return dx2.abs().mean() + dxdy.abs().mean() + dydx.abs().mean() + dy2.abs().mean()
