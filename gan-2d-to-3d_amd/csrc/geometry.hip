@@ -233,6 +233,145 @@ __global__ __launch_bounds__(256) void smooth_loss_bwd(const float *__restrict__
     gp[(size_t)blockIdx.z * H * W + y * W + x] = g * gloss[0];
 }
 
+// ------------------------------------------------------------------ normals from depth
+// renderer.py:127-139: g = d * ray; n = (g[y,x+1] - g[y,x-1]) x (g[y+1,x] - g[y-1,x]) in the interior,
+// (0,0,1) on the border; normal = n / (|n| + 1e-7).  grid (ceil(W/32), ceil(H/8), B), block (32, 8)
+constexpr float NORMAL_EPS = 1e-7f;
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+
+__device__ __forceinline__ V3 pt3(const float *d, const float *rays, int W, int y, int x) {
+    const float dd = d[y * W + x];
+    const float *r = rays + 3 * (y * W + x);
+    return V3{r[0] * dd, r[1] * dd, r[2] * dd};
+}
+
+__global__ __launch_bounds__(256) void normal_fwd(const float *__restrict__ depth,
+                                                  const float *__restrict__ rays,
+                                                  float *__restrict__ normal, int H, int W) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    const float *d = depth + (size_t)blockIdx.z * H * W;
+    V3 n{0.0f, 0.0f, 1.0f};
+    if (x > 0 && y > 0 && x < W - 1 && y < H - 1)
+        n = cross3(sub3(pt3(d, rays, W, y, x + 1), pt3(d, rays, W, y, x - 1)),
+                   sub3(pt3(d, rays, W, y + 1, x), pt3(d, rays, W, y - 1, x)));
+    const float inv = 1.0f / (sqrtf(n.x * n.x + n.y * n.y + n.z * n.z) + NORMAL_EPS);
+    float *o = normal + ((size_t)blockIdx.z * H * W + y * W + x) * 3;
+    o[0] = n.x * inv; o[1] = n.y * inv; o[2] = n.z * inv;
+}
+
+// gradient of the un-normalised normal n at interior pixel (y, x) -> (g_tu, g_tv)
+__device__ __forceinline__ void normal_tangent_grads(const float *d, const float *rays,
+                                                     const float *gnormal, int H, int W, int y, int x,
+                                                     V3 &gtu, V3 &gtv) {
+    gtu = V3{0, 0, 0};
+    gtv = V3{0, 0, 0};
+    if (!(x > 0 && y > 0 && x < W - 1 && y < H - 1)) return;
+    const V3 tu = sub3(pt3(d, rays, W, y, x + 1), pt3(d, rays, W, y, x - 1));
+    const V3 tv = sub3(pt3(d, rays, W, y + 1, x), pt3(d, rays, W, y - 1, x));
+    const V3 n = cross3(tu, tv);
+    const float r = sqrtf(n.x * n.x + n.y * n.y + n.z * n.z), re = r + NORMAL_EPS;
+    const float *g = gnormal + 3 * (y * W + x);
+    const float dot = n.x * g[0] + n.y * g[1] + n.z * g[2];
+    const float k = (r > 0.0f) ? dot / (re * re * r) : 0.0f;
+    const V3 gn{g[0] / re - n.x * k, g[1] / re - n.y * k, g[2] / re - n.z * k};
+    gtu = cross3(tv, gn);   // d(tu x tv)/d tu
+    gtv = cross3(gn, tu);   // d(tu x tv)/d tv
+}
+
+__global__ __launch_bounds__(256) void normal_bwd(const float *__restrict__ depth,
+                                                  const float *__restrict__ rays,
+                                                  const float *__restrict__ gnormal,
+                                                  float *__restrict__ gdepth, int H, int W) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    const float *d = depth + (size_t)blockIdx.z * H * W;
+    const float *gn = gnormal + (size_t)blockIdx.z * H * W * 3;
+    // g_point[p] = gtu(y, x-1) - gtu(y, x+1) + gtv(y-1, x) - gtv(y+1, x)
+    V3 a, b, acc{0, 0, 0};
+    if (x - 1 >= 0) { normal_tangent_grads(d, rays, gn, H, W, y, x - 1, a, b); acc.x += a.x; acc.y += a.y; acc.z += a.z; }
+    if (x + 1 < W) { normal_tangent_grads(d, rays, gn, H, W, y, x + 1, a, b); acc.x -= a.x; acc.y -= a.y; acc.z -= a.z; }
+    if (y - 1 >= 0) { normal_tangent_grads(d, rays, gn, H, W, y - 1, x, a, b); acc.x += b.x; acc.y += b.y; acc.z += b.z; }
+    if (y + 1 < H) { normal_tangent_grads(d, rays, gn, H, W, y + 1, x, a, b); acc.x -= b.x; acc.y -= b.y; acc.z -= b.z; }
+    const float *r = rays + 3 * (y * W + x);
+    gdepth[(size_t)blockIdx.z * H * W + y * W + x] = acc.x * r[0] + acc.y * r[1] + acc.z * r[2];
+}
+
+// ------------------------------------------------------------------ lighting + shading
+// model.py:347-360: a = l0/2+.5, b = l1/2+.5, dir = normalize(l2, l3, 1);
+// diffuse = relu(n . dir); shading = a + b * diffuse; texture = (albedo/2 + .5) * shading * 2 - 1.
+// normal [Bn,H,W,3] and albedo [Ba,3,H,W] broadcast over the light batch B (Bn, Ba in {1, B}).
+__global__ __launch_bounds__(256) void shading_fwd(const float *__restrict__ normal,
+                                                   const float *__restrict__ light,
+                                                   const float *__restrict__ albedo,
+                                                   float *__restrict__ diffuse,
+                                                   float *__restrict__ texture, int P, int Bn, int Ba) {
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float *l = light + b * 4;
+    const float la = l[0] / 2.0f + 0.5f, lb = l[1] / 2.0f + 0.5f;
+    const float nrm = sqrtf(l[2] * l[2] + l[3] * l[3] + 1.0f);
+    const float dx = l[2] / nrm, dy = l[3] / nrm, dz = 1.0f / nrm;
+    const float *n = normal + ((size_t)(Bn == 1 ? 0 : b) * P + p) * 3;
+    const float dot = n[0] * dx + n[1] * dy + n[2] * dz;
+    const float dif = dot > 0.0f ? dot : 0.0f;
+    diffuse[(size_t)b * P + p] = dif;
+    const float sh = la + lb * dif;
+    const float *al = albedo + (size_t)(Ba == 1 ? 0 : b) * 3 * P + p;
+    float *tx = texture + (size_t)b * 3 * P + p;
+    for (int c = 0; c < 3; c++) tx[(size_t)c * P] = (al[(size_t)c * P] / 2.0f + 0.5f) * sh * 2.0f - 1.0f;
+}
+
+// per-b gradients: gnormal [B,P,3], galbedo [B,3,P], glight [B,4] (zero-filled by the caller)
+__global__ __launch_bounds__(256) void shading_bwd(const float *__restrict__ normal,
+                                                   const float *__restrict__ light,
+                                                   const float *__restrict__ albedo,
+                                                   const float *__restrict__ gdiffuse,
+                                                   const float *__restrict__ gtexture,
+                                                   float *__restrict__ gnormal,
+                                                   float *__restrict__ galbedo,
+                                                   float *__restrict__ glight, int P, int Bn, int Ba) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = p < P;
+    const float *l = light + b * 4;
+    const float la = l[0] / 2.0f + 0.5f, lb = l[1] / 2.0f + 0.5f;
+    const float nrm = sqrtf(l[2] * l[2] + l[3] * l[3] + 1.0f);
+    const float dx = l[2] / nrm, dy = l[3] / nrm, dz = 1.0f / nrm;
+    float g_la = 0, g_lb = 0, g_dx = 0, g_dy = 0, g_dz = 0;
+    if (ok) {
+        const float *n = normal + ((size_t)(Bn == 1 ? 0 : b) * P + p) * 3;
+        const float dot = n[0] * dx + n[1] * dy + n[2] * dz;
+        const float dif = dot > 0.0f ? dot : 0.0f;
+        const float sh = la + lb * dif;
+        const float *al = albedo + (size_t)(Ba == 1 ? 0 : b) * 3 * P + p;
+        const float *gt = gtexture + (size_t)b * 3 * P + p;
+        float g_sh = 0.0f;
+        for (int c = 0; c < 3; c++) {
+            const float g = gt[(size_t)c * P];
+            g_sh += g * (al[(size_t)c * P] / 2.0f + 0.5f) * 2.0f;
+            galbedo[(size_t)b * 3 * P + (size_t)c * P + p] = g * sh;  // d/d albedo = 0.5 * sh * 2
+        }
+        float g_dif = g_sh * lb + (gdiffuse ? gdiffuse[(size_t)b * P + p] : 0.0f);
+        g_la = g_sh;
+        g_lb = g_sh * dif;
+        const float g_dot = dot > 0.0f ? g_dif : 0.0f;
+        float *gn = gnormal + ((size_t)b * P + p) * 3;
+        gn[0] = g_dot * dx; gn[1] = g_dot * dy; gn[2] = g_dot * dz;
+        g_dx = g_dot * n[0]; g_dy = g_dot * n[1]; g_dz = g_dot * n[2];
+    }
+    // direction = (l2, l3, 1) / nrm:  g_l2 = (g_dx - dx * (g . dir)) / nrm, same for l3
+    const float gd_dot = g_dx * dx + g_dy * dy + g_dz * dz;
+    float *o = glight + b * 4;
+    block_atomic_add(g_la * 0.5f, o + 0, red);
+    block_atomic_add(g_lb * 0.5f, o + 1, red);
+    block_atomic_add((g_dx - dx * gd_dot) / nrm, o + 2, red);
+    block_atomic_add((g_dy - dy * gd_dot) / nrm, o + 3, red);
+}
+
 static Intr make_intr(const float *K, int H, int W) {
     return Intr{K[0], K[1], K[2], K[3], K[4], K[5], 2.0f / (float)(W - 1), 2.0f / (float)(H - 1)};
 }
@@ -320,4 +459,41 @@ extern "C" int g2s_smooth_loss_bwd(const float *p, const float *gloss, float *gp
     smooth_weights(N, H, W, wxx, wxy, wyy);
     smooth_loss_bwd<<<dim3(cdiv(W, 32), cdiv(H, 8), N), 256, 0, as_stream(stream)>>>(p, gloss, gp, H, W, wxx, wxy, wyy);
     return check_launch("g2s_smooth_loss_bwd");
+}
+
+extern "C" int g2s_normal_fwd(const float *depth, const float *rays, float *normal, int B, int H, int W,
+                              g2s_stream_t stream) {
+    G2S_REQUIRE(depth && rays && normal && B > 0 && H > 0 && W > 0 && B <= 65535, "bad argument");
+    normal_fwd<<<dim3(cdiv(W, 32), cdiv(H, 8), B), 256, 0, as_stream(stream)>>>(depth, rays, normal, H, W);
+    return check_launch("g2s_normal_fwd");
+}
+
+extern "C" int g2s_normal_bwd(const float *depth, const float *rays, const float *gnormal, float *gdepth,
+                              int B, int H, int W, g2s_stream_t stream) {
+    G2S_REQUIRE(depth && rays && gnormal && gdepth && B > 0 && H > 0 && W > 0 && B <= 65535, "bad argument");
+    normal_bwd<<<dim3(cdiv(W, 32), cdiv(H, 8), B), 256, 0, as_stream(stream)>>>(depth, rays, gnormal, gdepth, H, W);
+    return check_launch("g2s_normal_bwd");
+}
+
+extern "C" int g2s_shading_fwd(const float *normal, const float *light, const float *albedo,
+                               float *diffuse, float *texture, int B, int Bn, int Ba, int P,
+                               g2s_stream_t stream) {
+    G2S_REQUIRE(normal && light && albedo && diffuse && texture && B > 0 && P > 0 && B <= 65535, "bad argument");
+    G2S_REQUIRE((Bn == 1 || Bn == B) && (Ba == 1 || Ba == B), "normal / albedo batch must be 1 or B");
+    shading_fwd<<<dim3(cdiv(P, 256), B), 256, 0, as_stream(stream)>>>(normal, light, albedo, diffuse, texture, P, Bn, Ba);
+    return check_launch("g2s_shading_fwd");
+}
+
+extern "C" int g2s_shading_bwd(const float *normal, const float *light, const float *albedo,
+                               const float *gdiffuse, const float *gtexture, float *gnormal,
+                               float *galbedo, float *glight, int B, int Bn, int Ba, int P,
+                               g2s_stream_t stream) {
+    G2S_REQUIRE(normal && light && albedo && gtexture && gnormal && galbedo && glight && B > 0 && P > 0 && B <= 65535,
+                "bad argument");
+    G2S_REQUIRE((Bn == 1 || Bn == B) && (Ba == 1 || Ba == B), "normal / albedo batch must be 1 or B");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(glight, 0, (size_t)B * 4 * sizeof(float), st) != hipSuccess)
+        return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
+    shading_bwd<<<dim3(cdiv(P, 256), B), 256, 0, st>>>(normal, light, albedo, gdiffuse, gtexture, gnormal, galbedo, glight, P, Bn, Ba);
+    return check_launch("g2s_shading_bwd");
 }

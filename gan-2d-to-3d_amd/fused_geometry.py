@@ -135,6 +135,82 @@ class SmoothLossFunction(Function):
         return gp.reshape(ctx.shape)
 
 
+class NormalFunction(Function):
+    """renderer.py:127-139 get_normal_from_depth."""
+
+    @staticmethod
+    def forward(ctx, depth, rays):
+        depth = _f32c(depth)
+        B, H, W = depth.shape
+        normal = torch.empty((B, H, W, 3), dtype=torch.float32, device=depth.device)
+        L = _lib.load()
+        _lib.check(L.g2s_normal_fwd(_lib.ptr(depth), _lib.ptr(rays), _lib.ptr(normal), B, H, W,
+                                    _lib.stream()))
+        ctx.save_for_backward(depth, rays)
+        return normal
+
+    @staticmethod
+    def backward(ctx, gnormal):
+        depth, rays = ctx.saved_tensors
+        B, H, W = depth.shape
+        gdepth = torch.empty_like(depth)
+        L = _lib.load()
+        _lib.check(L.g2s_normal_bwd(_lib.ptr(depth), _lib.ptr(rays), _lib.ptr(_f32c(gnormal)),
+                                    _lib.ptr(gdepth), B, H, W, _lib.stream()))
+        return gdepth, None
+
+
+class ShadingFunction(Function):
+    """model.py:347-360 get_lighting_directions + get_shading: light [B,4] (after the mean is added),
+    normal [Bn,H,W,3], albedo [Ba,3,H,W] with Bn, Ba in {1, B} -> diffuse [B,1,H,W], texture [B,3,H,W]."""
+
+    @staticmethod
+    def forward(ctx, normal, light, albedo):
+        normal, light, albedo = _f32c(normal), _f32c(light), _f32c(albedo)
+        B = light.shape[0]
+        Bn, H, W, _ = normal.shape
+        Ba = albedo.shape[0]
+        diffuse = torch.empty((B, 1, H, W), dtype=torch.float32, device=light.device)
+        texture = torch.empty((B, 3, H, W), dtype=torch.float32, device=light.device)
+        L = _lib.load()
+        _lib.check(L.g2s_shading_fwd(_lib.ptr(normal), _lib.ptr(light), _lib.ptr(albedo),
+                                     _lib.ptr(diffuse), _lib.ptr(texture), B, Bn, Ba, H * W,
+                                     _lib.stream()))
+        ctx.save_for_backward(normal, light, albedo)
+        return diffuse, texture
+
+    @staticmethod
+    def backward(ctx, gdiffuse, gtexture):
+        normal, light, albedo = ctx.saved_tensors
+        B = light.shape[0]
+        Bn, H, W, _ = normal.shape
+        Ba = albedo.shape[0]
+        dev = light.device
+        if gtexture is None:
+            gtexture = torch.zeros((B, 3, H, W), dtype=torch.float32, device=dev)
+        gnormal = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+        galbedo = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        glight = torch.empty((B, 4), dtype=torch.float32, device=dev)
+        gd = None if gdiffuse is None else _f32c(gdiffuse)
+        L = _lib.load()
+        _lib.check(L.g2s_shading_bwd(_lib.ptr(normal), _lib.ptr(light), _lib.ptr(albedo), _lib.ptr(gd),
+                                     _lib.ptr(_f32c(gtexture)), _lib.ptr(gnormal), _lib.ptr(galbedo),
+                                     _lib.ptr(glight), B, Bn, Ba, H * W, _lib.stream()))
+        if Bn == 1 and B > 1:
+            gnormal = gnormal.sum(0, keepdim=True)
+        if Ba == 1 and B > 1:
+            galbedo = galbedo.sum(0, keepdim=True)
+        return gnormal, glight, galbedo
+
+
+def normal_from_depth(depth, rays):
+    return NormalFunction.apply(depth, rays)
+
+
+def shading(normal, light, albedo):
+    return ShadingFunction.apply(normal, light, albedo)
+
+
 def view_transform(view, rot_scale=1.0, txy_scale=1.0, tz_scale=1.0):
     return ViewTransformFunction.apply(view, float(rot_scale), float(txy_scale), float(tz_scale))
 

@@ -36,6 +36,10 @@ SIGNATURES = {
     "g2s_warp_verts_bwd": (_i, [_p, _p, _p, _p, _f, _p, _p, _i, _i, _p]),
     "g2s_inv_warp_grid_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _p]),
     "g2s_inv_warp_grid_bwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p]),
+    "g2s_normal_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "g2s_normal_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "g2s_shading_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "g2s_shading_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "g2s_smooth_loss_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "g2s_smooth_loss_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
 }

@@ -156,6 +156,17 @@ class GAN2Shape(nn.Module):
         texture = (albedo / 2 + 0.5) * shading * 2 - 1
         return diffuse_shading, texture
 
+    def _shade(self, normal, lighting, albedo):
+        """get_lighting_directions + get_shading (model.py:347-360) -> (a, b, diffuse, texture);
+        one fused kernel on the GPU."""
+        if lighting.is_cuda and self.renderer.fused:
+            from .fused_geometry import shading
+            diffuse_shading, texture = shading(normal, lighting, albedo)
+            return lighting[:, :1] / 2 + 0.5, lighting[:, 1:2] / 2 + 0.5, diffuse_shading, texture
+        lighting_a, lighting_b, lighting_d = self.get_lighting_directions(lighting)
+        diffuse_shading, texture = self.get_shading(normal, lighting_a, lighting_b, lighting_d, albedo)
+        return lighting_a, lighting_b, diffuse_shading, texture
+
     def _no_grad_if(self, cond):
         return torch.no_grad() if cond else torch.enable_grad()
 
@@ -176,10 +187,9 @@ class GAN2Shape(nn.Module):
         with self._no_grad_if(step1):
             lighting = self.lighting_net(images)
         lighting = lighting + self.view_light_sampler.light_mean.unsqueeze(0)
-        lighting_a, lighting_b, lighting_d = self.get_lighting_directions(lighting)
 
         normal = self.renderer.get_normal_from_depth(depth)
-        diffuse_shading, texture = self.get_shading(normal, lighting_a, lighting_b, lighting_d, albedo)
+        lighting_a, lighting_b, diffuse_shading, texture = self._shade(normal, lighting, albedo)
 
         recon_depth = self.renderer.warp_canon_depth(depth)
         grid_2d_from_canon = self.renderer.get_inv_warped_2d_grid(recon_depth)
@@ -294,8 +304,7 @@ class GAN2Shape(nn.Module):
         view = self.viewpoint_net(projected_samples) + self.view_light_sampler.view_mean.unsqueeze(0)
         self._set_view(view)
         light = self.lighting_net(projected_samples) + self.view_light_sampler.light_mean.unsqueeze(0)
-        light_a, light_b, light_d = self.get_lighting_directions(light)
-        diffuse_shading, texture = self.get_shading(normal, light_a, light_b, light_d, albedo)
+        _, _, diffuse_shading, texture = self._shade(normal, light, albedo)
 
         depth = depth.expand(b, self.image_size, self.image_size)
         recon_depth = self.renderer.warp_canon_depth(depth)

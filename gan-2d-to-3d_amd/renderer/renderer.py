@@ -159,6 +159,8 @@ class Renderer():
 
     def get_normal_from_depth(self, depth):
         b, h, w = depth.shape
+        if self._use_fused(depth):
+            return fg.normal_from_depth(depth, self._pixel_rays(h, w, depth.device).reshape(-1, 3))
         grid_3d = self.depth_to_3d_grid(depth)
         tu = grid_3d[:, 1:-1, 2:] - grid_3d[:, 1:-1, :-2]
         tv = grid_3d[:, 2:, 1:-1] - grid_3d[:, :-2, 1:-1]

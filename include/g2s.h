@@ -195,6 +195,19 @@ int g2s_inv_warp_grid_fwd(const float *depth, const float *rays, const float *R,
 int g2s_inv_warp_grid_bwd(const float *depth, const float *rays, const float *R, const float *t,
                           const float *K, float rot_center_depth, const float *ggrid, float *gdepth,
                           float *gRt, int B, int H, int W, g2s_stream_t stream);
+/*   g2s_normal_*      normal [B,H,W,3] from depth (renderer.py:127-139), gradient to depth
+ *   g2s_shading_*     light [B,4] (a, b, dx, dy raw), normal [Bn,H,W,3], albedo [Ba,3,H,W] (Bn, Ba in
+ *                     {1, B}) -> diffuse [B,1,H,W], texture [B,3,H,W] (model.py:347-360); backward
+ *                     writes per-sample gnormal [B,H,W,3], galbedo [B,3,H,W] and glight [B,4]. */
+int g2s_normal_fwd(const float *depth, const float *rays, float *normal, int B, int H, int W,
+                   g2s_stream_t stream);
+int g2s_normal_bwd(const float *depth, const float *rays, const float *gnormal, float *gdepth, int B,
+                   int H, int W, g2s_stream_t stream);
+int g2s_shading_fwd(const float *normal, const float *light, const float *albedo, float *diffuse,
+                    float *texture, int B, int Bn, int Ba, int P, g2s_stream_t stream);
+int g2s_shading_bwd(const float *normal, const float *light, const float *albedo,
+                    const float *gdiffuse, const float *gtexture, float *gnormal, float *galbedo,
+                    float *glight, int B, int Bn, int Ba, int P, g2s_stream_t stream);
 int g2s_smooth_loss_fwd(const float *p, float *loss, int N, int H, int W, g2s_stream_t stream);
 int g2s_smooth_loss_bwd(const float *p, const float *gloss, float *gp, int N, int H, int W,
                         g2s_stream_t stream);

@@ -282,6 +282,45 @@ def test_fused_geometry_matches_torch_path():
     torch.testing.assert_close(g1, g2, rtol=1e-5, atol=1e-8)
 
 
+def test_fused_normal_and_shading_match_torch_path():
+    import gan2shape_amd  # noqa: F401
+    import bench
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.renderer import Renderer
+    torch.manual_seed(0)
+    S = 48
+    R = Renderer({"rot_center_depth": 1.0, "fov": 10}, S, 0.9, 1.1, device="cuda")
+    d0 = 0.9 + 0.2 * torch.rand(2, S, S, device="cuda")
+    w = torch.randn(2, S, S, 3, device="cuda")
+    res = {}
+    for fused in (True, False):
+        R.fused = fused
+        d = d0.clone().requires_grad_(True)
+        n = R.get_normal_from_depth(d)
+        (g,) = torch.autograd.grad((n * w).sum(), d)
+        res[fused] = (n, g)
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=1e-3, atol=1e-3 * float(res[False][1].abs().max()))
+
+    m = GAN2Shape.__new__(GAN2Shape)          # only the shading helpers are exercised
+    torch.nn.Module.__init__(m)
+    m.renderer = R
+    for B, Bn, Ba in [(3, 3, 3), (4, 1, 1), (1, 1, 1)]:
+        normal0 = torch.nn.functional.normalize(torch.randn(Bn, S, S, 3, device="cuda"), dim=3)
+        light0 = torch.randn(B, 4, device="cuda") * 0.5
+        albedo0 = torch.tanh(torch.randn(Ba, 3, S, S, device="cuda"))
+        wt, wd = torch.randn(B, 3, S, S, device="cuda"), torch.randn(B, 1, S, S, device="cuda")
+        out = {}
+        for fused in (True, False):
+            R.fused = fused
+            n_, l_, a_ = (t.clone().requires_grad_(True) for t in (normal0, light0, albedo0))
+            la, lb, dif, tex = m._shade(n_, l_, a_)
+            loss = (tex * wt).sum() + (dif * wd).sum() + la.sum() * 0.3 + lb.sum() * 0.7
+            out[fused] = (la, lb, dif, tex) + torch.autograd.grad(loss, (n_, l_, a_))
+        for x, y in zip(out[True], out[False]):
+            torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-5 * (1 + float(y.abs().max())))
+
+
 def _smooth_ref(pred):
     """losses.py:54-79 in plain torch ops."""
     p = pred.reshape(-1, pred.size(-2), pred.size(-1))
