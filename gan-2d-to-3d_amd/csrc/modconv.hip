@@ -47,6 +47,9 @@ struct ConvDesc {
     int ncls;
     int splitk;
     int w_bytes;         // size of w in bytes (buffer-resource range)
+    const float *bias;   // [M] added after out_scale, or NULL
+    int act;             // 0: none, 1: leaky-ReLU(alpha) * gain applied after the bias
+    float act_alpha, act_gain;
     ConvClass cls[4];
 };
 
@@ -285,6 +288,8 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
                 if (m >= d.M) continue;
                 float v = acc[i][j][r];
                 if (ob) v *= ob[m];
+                if (d.bias) v += d.bias[m];
+                if (d.act) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
                 float *dst = yb + (size_t)m * d.OHf * d.OWf;
                 if (d.splitk > 1) unsafeAtomicAdd(dst, v);
                 else *dst = v;
@@ -343,9 +348,10 @@ static int pack(int dy, int dx, int wt) { return (dy + 8) | ((dx + 8) << 8) | (w
 
 using namespace g2s;
 
-extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale,
-                           const float *out_scale, float *y, int B, int Cin, int Cout, int H, int W,
-                           int k, int mode, int transpose, g2s_stream_t stream) {
+static int modconv_launch(const float *x, const float *w, const float *in_scale,
+                          const float *out_scale, const float *bias, int act, float act_alpha,
+                          float act_gain, float *y, int B, int Cin, int Cout, int H, int W, int k,
+                          int mode, int transpose, g2s_stream_t stream) {
     G2S_REQUIRE(x && w && y, "x, w, y must not be NULL");
     G2S_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "sizes must be positive");
     G2S_REQUIRE(k == 1 || k == 3, "kernel size must be 1 or 3 (got %d)", k);
@@ -356,6 +362,10 @@ extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale
     d.w = w;
     d.in_scale = in_scale;
     d.out_scale = out_scale;
+    d.bias = bias;
+    d.act = act;
+    d.act_alpha = act_alpha;
+    d.act_gain = act_gain;
     d.y = y;
     d.B = B;
     d.H = H;
@@ -433,6 +443,13 @@ extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale
     const int tiles = cdiv(d.M, BMv) * cdiv(nmax, BNv);
     int splitk = 1;
     while ((long)tiles * d.ncls * splitk < 512 && kt_min / (splitk * 2) >= 8 && splitk < 64) splitk *= 2;
+    // A bias / activation epilogue needs the complete sum: with split-K it runs as a second,
+    // elementwise launch (g2s_fused_bias_act in place) after the partial sums have been added.
+    const bool deferred_epilogue = splitk > 1 && (bias != nullptr || act != 0);
+    if (deferred_epilogue) {
+        d.bias = nullptr;
+        d.act = 0;
+    }
     d.splitk = splitk;
     if (splitk > 1 || (scatter && k == 1)) {
         if (hipMemsetAsync(y, 0, (size_t)B * d.M * d.OHf * d.OWf * sizeof(float), st) != hipSuccess)
@@ -442,5 +459,24 @@ extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale
     if (pick == 0) modconv_kernel<128, 128><<<grid, NTHREADS, 0, st>>>(d);
     else if (pick == 1) modconv_kernel<128, 64><<<grid, NTHREADS, 0, st>>>(d);
     else modconv_kernel<64, 64><<<grid, NTHREADS, 0, st>>>(d);
-    return check_launch("g2s_modconv");
+    int rc = check_launch("g2s_modconv");
+    if (rc != G2S_OK || !deferred_epilogue) return rc;
+    return g2s_fused_bias_act(y, bias, nullptr, y, (int64_t)B * d.M * d.OHf * d.OWf,
+                              (int64_t)d.OHf * d.OWf, d.M, act ? 3 : 1, 0, act_alpha,
+                              act ? act_gain : 1.0f, G2S_F32, stream);
+}
+
+extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale,
+                           const float *out_scale, float *y, int B, int Cin, int Cout, int H, int W,
+                           int k, int mode, int transpose, g2s_stream_t stream) {
+    return modconv_launch(x, w, in_scale, out_scale, nullptr, 0, 0.0f, 1.0f, y, B, Cin, Cout, H, W, k,
+                          mode, transpose, stream);
+}
+
+extern "C" int g2s_conv_bias_act(const float *x, const float *w, const float *bias, float *y, int B,
+                                 int Cin, int Cout, int H, int W, int k, int mode, int act,
+                                 float alpha, float gain, g2s_stream_t stream) {
+    G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
+    return modconv_launch(x, w, nullptr, nullptr, bias, act, alpha, gain, y, B, Cin, Cout, H, W, k,
+                          mode, 0, stream);
 }

@@ -77,9 +77,18 @@ class VGG16Features(nn.Module):
             p.requires_grad = False
 
     def forward(self, x):
+        fused = x.is_cuda and x.dtype == torch.float32 and not any(p.requires_grad for p in self.parameters())
         outs = []
         for si in range(5):
-            x = getattr(self, f"slice{si + 1}")(x)
+            if fused:  # conv + bias + ReLU in one launch of the MFMA kernel (frozen weights)
+                from .modconv import conv_bias_relu
+                for mod in getattr(self, f"slice{si + 1}"):
+                    if isinstance(mod, nn.Conv2d):
+                        x = conv_bias_relu(x, mod.weight, mod.bias)
+                    elif isinstance(mod, nn.MaxPool2d):
+                        x = mod(x)
+            else:
+                x = getattr(self, f"slice{si + 1}")(x)
             outs.append(x)
         return outs
 

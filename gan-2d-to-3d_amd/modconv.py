@@ -217,3 +217,35 @@ def conv2d_supported(x, w, stride, padding):
 
 def conv2d(x, w, mode):
     return PlainConvFunction.apply(x, w, mode)
+
+
+class ConvBiasReluFunction(Function):
+    """relu(conv3x3(x, w, padding=1) + bias) for a FROZEN network (no weight / bias gradient): the
+    VGG16 trunk of LPIPS (lpips/pretrained_networks.py:97-135).  Forward is one launch
+    (g2s_conv_bias_act); backward = ReLU mask (g2s_fused_bias_act, act 3 / grad 1 / alpha 0) + the
+    data-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, w, bias = x.contiguous(), w.contiguous(), bias.contiguous()
+        B, Cin, H, W = x.shape
+        Cout, _, k, _ = w.shape
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        L = _lib.load()
+        _lib.check(L.g2s_conv_bias_act(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cin,
+                                       Cout, H, W, k, PLAIN, 1, 0.0, 1.0, _lib.stream()))
+        ctx.save_for_backward(w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        w, y = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        from .plugins import fused
+        g = fused.fused_bias_act(gy.contiguous(), gy.new_empty(0), y, 3, 1, 0.0, 1.0)
+        return modconv_raw(g, w, None, None, PLAIN, 1), None, None
+
+
+def conv_bias_relu(x, w, bias):
+    return ConvBiasReluFunction.apply(x, w, bias)

@@ -142,6 +142,14 @@ int g2s_modconv(const float *x, const float *w, const float *in_scale, const flo
                 float *y, int B, int Cin, int Cout, int H, int W, int k, int mode, int transpose,
                 g2s_stream_t stream);
 
+/* Plain convolution on the same kernel with a fused epilogue:
+ *   y = act(conv(x, w) + bias[o]),  act = 0: identity, 1: leaky-ReLU(alpha) * gain (alpha = 0, gain = 1: ReLU).
+ * Used for the frozen VGG16 of the LPIPS loss (conv3x3 + bias + ReLU, lpips/pretrained_networks.py:97-135).
+ * Same geometry modes as g2s_modconv with transpose = 0; bias may be NULL. */
+int g2s_conv_bias_act(const float *x, const float *w, const float *bias, float *y, int B, int Cin,
+                      int Cout, int H, int W, int k, int mode, int act, float alpha, float gain,
+                      g2s_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Row-wise fused reductions around the modulated convolution (csrc/rowops.hip).
  * g2s_rows_dot_scale: a, b, out are [rows, n] f32; s, inv, dot are [rows].

@@ -328,3 +328,30 @@ def _smooth_ref(pred):
     dx2, dxdy = dx[:, :, 1:] - dx[:, :, :-1], dx[:, 1:] - dx[:, :-1]
     dydx, dy2 = dy[:, :, 1:] - dy[:, :, :-1], dy[:, 1:] - dy[:, :-1]
     return dx2.abs().mean() + dxdy.abs().mean() + dydx.abs().mean() + dy2.abs().mean()
+
+
+def test_vgg_trunk_on_mfma_kernel_matches_miopen():
+    """conv3x3 + bias + ReLU through g2s_conv_bias_act vs torch.nn (MIOpen), features and the
+    gradient w.r.t. the input image."""
+    import gan2shape_amd  # noqa: F401
+    from gan2shape_amd.lpips import VGG16Features
+    torch.manual_seed(0)
+    v = VGG16Features().cuda()
+    for B in (1, 3):
+        x0 = torch.rand(B, 3, 64, 64, device="cuda") * 2 - 1
+        res = {}
+        for fused in (True, False):
+            next(v.parameters()).requires_grad_(not fused)   # a trainable weight forces the torch path
+            x = x0.clone().requires_grad_(True)
+            feats = v(x)
+            loss = sum((f * f).mean() for f in feats)
+            (g,) = torch.autograd.grad(loss, x)
+            res[fused] = (feats, g)
+        next(v.parameters()).requires_grad_(False)
+        for a, b in zip(res[True][0], res[False][0]):
+            torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-4 * float(b.abs().max()))
+        # a feature within rounding of zero may flip its ReLU gate between the two summation
+        # orders: compare the gradients in the L2 sense, and bound the worst element loosely
+        ga, gb = res[True][1], res[False][1]
+        assert float((ga - gb).norm() / gb.norm()) < 2e-3
+        assert float((ga - gb).abs().max()) < 2e-2 * float(gb.abs().max())
