@@ -17,6 +17,6 @@ out = {"kernel": "g2s::modconv_kernel", "launches_fetch_pass": nf, "launches_wri
        "fetch_bytes_per_launch": 2 * f * 1024, "write_bytes_per_launch": w * 1024,
        "traffic_bytes_per_launch": 2 * f * 1024 + w * 1024,
        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE x1",
-       "command": "rocprofv3 --pmc <counter> -- python bench.py --eager --steps 20 --warmup 0 --no-cpu-baseline"}
+       "command": "rocprofv3 --pmc <counter> -- python tools/pmc_iter.py"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
