@@ -228,9 +228,18 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        runner.run(PATTERN[i % len(PATTERN)], timed=True)
+        runner.run(PATTERN[i % len(PATTERN)])
     barrier()
     elapsed = time.perf_counter() - t0
+    # per-kind times (report only): a few iterations of each kind, outside the timed region —
+    # recording events between graph launches costs ~1 ms per iteration
+    for kind in sorted(set(PATTERN)):
+        torch.cuda.synchronize()
+        tk = time.perf_counter()
+        for _ in range(10):
+            runner.run(kind)
+        torch.cuda.synchronize()
+        runner.kind_ms[kind] = (time.perf_counter() - tk) / 10 * 1e3
     if not args.eager:
         mc.PROFILE = []
         for kind in PATTERN:
@@ -242,8 +251,7 @@ def main():
     rate, elapsed = sharding.job_throughput(args.steps, elapsed, device)
 
     if rank == 0:
-        kind_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else None)
-                   for k, v in runner.kind_ms.items()}
+        kind_ms = {k: (v if not isinstance(v, list) else None) for k, v in runner.kind_ms.items()}
         flops = sum(p[0] for p in prof)
         ms = sum(p[1].elapsed_time(p[2]) for p in prof)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

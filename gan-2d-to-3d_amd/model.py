@@ -172,20 +172,30 @@ class GAN2Shape(nn.Module):
 
     # ------------------------------------------------------------------ step 1
     def forward_step1(self, images, latents, collected, step1=True, eval=False, **kwargs):
-        """model.py:95-173: optimise the albedo net (step1=True) / everything (step1=False)."""
+        """model.py:95-173: optimise the albedo net (step1=True) / everything (step1=False).
+
+        `_view_light`, `_defer_perc` are internal (forward_step3 batches the image with its projected
+        samples through V / L and through LPIPS; the arithmetic per sample is unchanged)."""
         b = 1
         h, w = self.image_size, self.image_size
         with self._no_grad_if(step1):
             depth_raw = self.depth_net(images)
         depth = self.get_clamped_depth(depth_raw.squeeze(1), h, w)
-        with self._no_grad_if(step1):
-            view = self.viewpoint_net(images)
+        pre = kwargs.get('_view_light')
+        if pre is None:
+            with self._no_grad_if(step1):
+                view = self.viewpoint_net(images)
+        else:
+            view = pre[0]
         view = view + self.view_light_sampler.view_mean.unsqueeze(0)
         self._set_view(view)
 
         albedo = self.albedo_net(images)
-        with self._no_grad_if(step1):
-            lighting = self.lighting_net(images)
+        if pre is None:
+            with self._no_grad_if(step1):
+                lighting = self.lighting_net(images)
+        else:
+            lighting = pre[1]
         lighting = lighting + self.view_light_sampler.light_mean.unsqueeze(0)
 
         normal = self.renderer.get_normal_from_depth(depth)
@@ -202,14 +212,15 @@ class GAN2Shape(nn.Module):
             return recon_im, recon_depth
 
         loss_l1_im = self.photometric_loss(recon_im[:b], images, mask=recon_im_mask[:b])
-        loss_perc_im = self.perceptual_loss(recon_im[:b] * recon_im_mask[:b],
-                                            images * recon_im_mask[:b])
-        loss_perc_im = torch.mean(loss_perc_im)
+        perc_pair = (recon_im[:b] * recon_im_mask[:b], images * recon_im_mask[:b])
         loss_smooth = self.smooth_loss(depth) + self.smooth_loss(diffuse_shading)
-        loss_total = loss_l1_im + self.lam_perc * loss_perc_im + self.lam_smooth * loss_smooth
-
         canon_mask = None if len(images) == 1 else [None] * len(images)
-        return loss_total, (normal, lighting_a, lighting_b, albedo, depth, canon_mask)
+        collected = (normal, lighting_a, lighting_b, albedo, depth, canon_mask)
+        if kwargs.get('_defer_perc'):  # caller adds lam_perc * mean(LPIPS(*perc_pair))
+            return loss_l1_im + self.lam_smooth * loss_smooth, collected, perc_pair
+        loss_perc_im = torch.mean(self.perceptual_loss(*perc_pair))
+        loss_total = loss_l1_im + self.lam_perc * loss_perc_im + self.lam_smooth * loss_smooth
+        return loss_total, collected
 
     # ------------------------------------------------------------------ step 2
     def _latent_centers(self):
@@ -297,13 +308,27 @@ class GAN2Shape(nn.Module):
         torch.randperm(len(projected_samples))
         projected_samples, masks = projected_samples.to(self.device), masks.to(self.device)
 
-        step1_loss, collected = self.forward_step1(images, None, None, step1=False)
+        # V and L see the image and its projected samples in ONE batch (1 + n), and so does LPIPS
+        # below: the reference runs them as two calls each (model.py:113-131,243-250 and :159,275);
+        # per-sample results are unchanged (no batch statistics in these nets), launches halve.
+        b = len(projected_samples)
+        both = torch.cat([images[:1], projected_samples], 0) if len(images) == 1 else None
+        if both is not None:
+            view_all = self.viewpoint_net(both)
+            light_all = self.lighting_net(both)
+            step1_loss, collected, perc1 = self.forward_step1(
+                images, None, None, step1=False, _view_light=(view_all[:1], light_all[:1]),
+                _defer_perc=True)
+            view, light = view_all[1:], light_all[1:]
+        else:
+            step1_loss, collected = self.forward_step1(images, None, None, step1=False)
+            perc1 = None
+            view, light = self.viewpoint_net(projected_samples), self.lighting_net(projected_samples)
         normal, _, _, albedo, depth, _ = collected
 
-        b = len(projected_samples)
-        view = self.viewpoint_net(projected_samples) + self.view_light_sampler.view_mean.unsqueeze(0)
+        view = view + self.view_light_sampler.view_mean.unsqueeze(0)
         self._set_view(view)
-        light = self.lighting_net(projected_samples) + self.view_light_sampler.light_mean.unsqueeze(0)
+        light = light + self.view_light_sampler.light_mean.unsqueeze(0)
         _, _, diffuse_shading, texture = self._shade(normal, light, albedo)
 
         depth = depth.expand(b, self.image_size, self.image_size)
@@ -315,9 +340,13 @@ class GAN2Shape(nn.Module):
                                  align_corners=True).clamp(min=-1, max=1)
 
         loss_l1_im = self.photometric_loss(recon_im[:b], projected_samples, mask=recon_im_mask[:b])
-        loss_perc_im = self.perceptual_loss(recon_im[:b] * recon_im_mask[:b],
-                                            projected_samples * recon_im_mask[:b])
-        loss_perc_im = torch.mean(loss_perc_im)
+        pred, target = recon_im[:b] * recon_im_mask[:b], projected_samples * recon_im_mask[:b]
+        if perc1 is not None:
+            perc = self.perceptual_loss(torch.cat([perc1[0], pred], 0), torch.cat([perc1[1], target], 0))
+            loss_perc_1, loss_perc_im = torch.mean(perc[:1]), torch.mean(perc[1:])
+            step1_loss = step1_loss + self.lam_perc * loss_perc_1
+        else:
+            loss_perc_im = torch.mean(self.perceptual_loss(pred, target))
         return step1_loss + loss_l1_im + self.lam_perc * loss_perc_im, None
 
     # ------------------------------------------------------------------ evaluation / checkpoints

@@ -355,3 +355,42 @@ def test_vgg_trunk_on_mfma_kernel_matches_miopen():
         ga, gb = res[True][1], res[False][1]
         assert float((ga - gb).norm() / gb.norm()) < 2e-3
         assert float((ga - gb).abs().max()) < 2e-2 * float(gb.abs().max())
+
+
+def test_step3_batched_nets_equal_reference_order(trainer):
+    """forward_step3 runs V / L / LPIPS once on (image + projected samples); the reference calls
+    them twice (model.py:113-131,243-250,159,275).  Same loss and gradients."""
+    import torch.nn.functional as F
+    m = trainer.model
+    image, latent = trainer.sample
+    with torch.no_grad():
+        _, col1 = m.forward_step1(image, latent, None)
+        torch.manual_seed(3)
+        _, col2 = m.forward_step2(image, latent, col1, n_proj_samples=3)
+    _zero(m)
+    loss_b, _ = m.forward_step3(image, latent, col2)
+    loss_b.backward()
+    gb = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    # reference order, literally (two calls of each net / of LPIPS)
+    _zero(m)
+    projected, masks = col2
+    step1_loss, collected = m.forward_step1(image, None, None, step1=False)
+    normal, _, _, albedo, depth, _ = collected
+    b = len(projected)
+    view = m.viewpoint_net(projected) + m.view_light_sampler.view_mean.unsqueeze(0)
+    m._set_view(view)
+    light = m.lighting_net(projected) + m.view_light_sampler.light_mean.unsqueeze(0)
+    _, _, _, texture = m._shade(normal, light, albedo)
+    recon_depth = m.renderer.warp_canon_depth(depth.expand(b, 128, 128))
+    grid = m.renderer.get_inv_warped_2d_grid(recon_depth)
+    mask = (recon_depth < 1.2).float().unsqueeze(1).detach() * masks
+    recon = F.grid_sample(texture, grid, mode='bilinear', align_corners=True).clamp(min=-1, max=1)
+    loss_r = step1_loss + m.photometric_loss(recon, projected, mask=mask) + \
+        torch.mean(m.perceptual_loss(recon * mask, projected * mask))
+    loss_r.backward()
+    assert abs(loss_b.item() - loss_r.item()) < 2e-5 * abs(loss_r.item())
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            ref = p.grad
+            assert float((gb[n] - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-9, n
