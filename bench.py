@@ -210,6 +210,7 @@ def main():
         graphed.collected = dict(runner.collected)
         for kind in (1, 2, 3):
             graphed.capture(kind)
+            graphed.run(kind)   # a capture only records: one replay fills the hand-off buffers
         runner = GraphedRunner(graphed)
     for i in range(args.warmup):
         runner.run(PATTERN[i % len(PATTERN)])

@@ -48,8 +48,8 @@ class GraphedSteps:
 
     def capture(self, kind):
         """Warm up `warmup` eager iterations on a side stream (library handles, autotuning, lazily
-        built caches), then capture one iteration.  Warm-up iterations are real training
-        iterations; callers that count iterations must count them."""
+        built caches), then capture one iteration (recorded, not executed).  Warm-up iterations are
+        real training iterations; callers that count iterations must count them (return value)."""
         optim = getattr(self.t, f'optim_step{kind}')
         src = self._source(kind)
         if kind > 1 and src is None:
@@ -68,7 +68,7 @@ class GraphedSteps:
         self.graphs[kind] = g
         self.loss[kind] = loss.detach()
         self.collected[kind] = collected
-        return self.warmup + 1  # iterations actually executed (capture runs the iteration once)
+        return self.warmup  # iterations actually executed (a stream capture records, it does not run)
 
     def run(self, kind):
         """One training iteration of kind `kind` (graph replay)."""

@@ -60,7 +60,11 @@ class Trainer():
 
     def fit(self, images_latents, plot_depth_map=False,
             stages=[{'step1': 1, 'step2': 1, 'step3': 1}] * 2, shuffle=False,
-            rank=0, world_size=1, **_):
+            rank=0, world_size=1, graphs=False, **_):
+        """graphs=True replays each step kind as a HIP graph (graphs.py): same iterations, same
+        order; needs Trainer(..., capturable=True) and a non-default current stream."""
+        if graphs:
+            return self._fit_graphed(images_latents, stages, shuffle, rank, world_size)
         total_it = 0
         n_stages = len(stages)
         data = images_latents
@@ -95,6 +99,42 @@ class Trainer():
             if self.save_ckpts:
                 self.model.save_checkpoint(data_index, stage, total_it, self.category)
         logging.info('Finished Training')
+        return total_it
+
+    def _fit_graphed(self, images_latents, stages, shuffle, rank, world_size):
+        from .graphs import GraphedSteps
+        if not self.capturable:
+            raise RuntimeError("graphs=True needs Trainer(..., capturable=True)")
+        data = images_latents
+        if world_size > 1:
+            data = Subset(images_latents, shard_indices(len(images_latents), rank, world_size))
+        dataloader = DataLoader(data, batch_size=1, shuffle=shuffle, num_workers=self.n_workers)
+        total_it = 0
+        graphed = None
+        for image, latent, data_index in dataloader:
+            image, latent = image.to(self.device), latent.to(self.device)
+            data_index = int(data_index[0])
+            if not self.debug and self.load_dict is None:
+                self.pretrain_on_prior(image, data_index)
+            if graphed is None:
+                graphed = GraphedSteps(self, image, latent)
+            else:
+                graphed.set_sample(image, latent)   # graphs read the static image / latent buffers
+            for stage in range(len(stages)):
+                for step in [1, 2, 3]:
+                    n = stages[stage][f'step{step}']
+                    done = 0
+                    if n > 0 and step not in graphed.graphs:
+                        if step > 1 and graphed.collected[step - 1] is None:
+                            raise RuntimeError(f"step {step} needs at least one step-{step - 1} iteration first")
+                        done = graphed.capture(step)     # the warm-up iterations are real iterations
+                    for _ in range(max(n - done, 0)):
+                        graphed.run(step)
+                    total_it += max(n, done) if n > 0 else 0
+                    if n > 0:
+                        self.history.append((data_index, stage, step, float(graphed.loss[step])))
+            if self.save_ckpts:
+                self.model.save_checkpoint(data_index, len(stages) - 1, total_it, self.category)
         return total_it
 
     def pretrain_on_prior(self, image, i_batch, plot_depth_map=False):
