@@ -70,6 +70,7 @@ class StepRunner:
         self.t, self.image, self.latent = trainer, image, latent
         self.collected = {1: None, 2: None, 3: None}
         self.kind_ms = {1: [], 2: [], 3: []}
+        self.last_loss = {}
 
     def run(self, kind, timed=False):
         t = self.t
@@ -87,6 +88,7 @@ class StepRunner:
             e1.record()
             self.kind_ms[kind].append((e0, e1))
         self.collected[kind] = collected
+        self.last_loss[kind] = loss.detach()
         return loss
 
 
@@ -96,6 +98,7 @@ class GraphedRunner:
     def __init__(self, graphed):
         self.g = graphed
         self.kind_ms = {1: [], 2: [], 3: []}
+        self.last_loss = graphed.loss
 
     def run(self, kind, timed=False):
         if timed:
@@ -251,6 +254,9 @@ def main():
     # whole-job rate: iterations of all ranks / the slowest rank's barrier-bracketed time
     rate, elapsed = sharding.job_throughput(args.steps, elapsed, device)
 
+    final_loss = {f"step{k}": float(v) for k, v in sorted(runner.last_loss.items())}
+    if not all(math.isfinite(v) for v in final_loss.values()):
+        raise RuntimeError(f"non-finite training loss after the timed region: {final_loss}")
     if rank == 0:
         kind_ms = {k: (v if not isinstance(v, list) else None) for k, v in runner.kind_ms.items()}
         flops = sum(p[0] for p in prof)
@@ -286,6 +292,7 @@ def main():
                        "images_per_rank": 1, "sharding": "one image per rank, no collective"},
             "ms_per_step_kind": {f"step{k}": v for k, v in kind_ms.items()},
             "launch_mode": "eager" if args.eager else "hipGraph replay (one graph per step kind)",
+            "final_loss": final_loss,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
