@@ -9,7 +9,8 @@
 //           faces (explicit topology): project vertices once, reduce the block's bounding box.
 //   tiles   one wavefront per 8x8-sample tile, 4 tiles (16x16 samples) per workgroup, no barriers:
 //             1. lanes test chunk boxes against the tile, wave-ballot the survivors;
-//             2. per surviving chunk, lane = quad / face: front-face test + face box test, ballot
+//             2. per surviving chunk, lane = quad / face: front-face test + face box test + exact
+//                (conservative) triangle-vs-tile edge test, ballot
 //                + mbcnt compaction of the surviving oriented faces into a per-wave LDS list;
 //             3. lane = sample: walk the list with LDS broadcast reads, three edge inequalities per
 //                face, remember covering faces (up to 8 byte-indices in a 64-bit register);
@@ -205,12 +206,14 @@ __device__ __forceinline__ void bin_triangle(Lists &L, int &count, bool valid, c
     const float bymin = fminf(p0.y, fminf(p1.y, p2.y)), bymax = fmaxf(p0.y, fmaxf(p1.y, p2.y));
     const bool ov = valid && bbox_overlaps(bxmin, bymin, bxmax, bymax, txlo, tylo, txhi, tyhi);
     {
-        const bool pass = ov && !back_facing(p0.x, p0.y, p1.x, p1.y, p2.x, p2.y);
+        const bool pass = ov && !back_facing(p0.x, p0.y, p1.x, p1.y, p2.x, p2.y) &&
+                          tile_may_cover(p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, txlo, tylo, txhi, tyhi);
         append(L, count, pass, make_rec(p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, g),
                lane, s, p);
     }
     if (p.fill_back) {  // reversed copy: vertex order (p2, p1, p0), id g + F
-        const bool pass = ov && !back_facing(p2.x, p2.y, p1.x, p1.y, p0.x, p0.y);
+        const bool pass = ov && !back_facing(p2.x, p2.y, p1.x, p1.y, p0.x, p0.y) &&
+                          tile_may_cover(p2.x, p2.y, p1.x, p1.y, p0.x, p0.y, txlo, tylo, txhi, tyhi);
         append(L, count, pass,
                make_rec(p2.x, p2.y, p2.z, p1.x, p1.y, p1.z, p0.x, p0.y, p0.z, g + p.F), lane, s, p);
     }

@@ -61,6 +61,28 @@ G2S_HD bool bbox_overlaps(float bxmin, float bymin, float bxmax, float bymax, fl
     return (bxmin - e <= txhi) && (bxmax + e >= txlo) && (bymin - e <= tyhi) && (bymax + e >= tylo);
 }
 
+// Conservative triangle-vs-tile test for the ordered (front-facing) face (a, b, c): the kernel_2
+// coverage test accepts a sample iff all three edge values  E_k(p) = (yp - y_k) * dx_k - (xp - x_k) * dy_k
+// are >= 0.  E_k is linear in p, so its maximum over the tile's sample-centre rectangle is attained
+// at a corner; if that maximum is negative (beyond a rounding margin) for any edge, no sample of
+// the tile can be covered.  This removes long thin faces (depth discontinuities seen from the
+// side) from every tile of their bounding box that they do not actually cross.
+G2S_HD bool edge_may_reach(float x0, float y0, float dx, float dy, float txlo, float tylo,
+                           float txhi, float tyhi) {
+    const float yp = dx > 0.0f ? tyhi : tylo;
+    const float xp = dy > 0.0f ? txlo : txhi;
+    const float a = (yp - y0) * dx, b = (xp - x0) * dy;
+    const float aa = a < 0.0f ? -a : a, bb = b < 0.0f ? -b : b;
+    return a - b >= -1e-5f * (aa + bb) - 1e-12f;
+}
+
+G2S_HD bool tile_may_cover(float ax, float ay, float bx, float by, float cx, float cy, float txlo,
+                           float tylo, float txhi, float tyhi) {
+    return edge_may_reach(ax, ay, bx - ax, by - ay, txlo, tylo, txhi, tyhi) &&
+           edge_may_reach(bx, by, cx - bx, cy - by, txlo, tylo, txhi, tyhi) &&
+           edge_may_reach(cx, cy, ax - cx, ay - cy, txlo, tylo, txhi, tyhi);
+}
+
 // One candidate face in the tile list: the three float4 the coverage test reads, plus depths/id.
 struct FaceRec {
     F4 e0;  // x0, y0, x1-x0, y1-y0

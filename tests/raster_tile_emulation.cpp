@@ -25,14 +25,14 @@ void grow(Box &b, const P4 &p) {
 extern "C" int g2s_emul_render_depth(const float *verts, const int *faces, int B, int N, int F, int S,
                                      const float *K, float orig_size, int ssaa, int fill_back,
                                      float near_, float far_, float *depth_out, int *face_idx,
-                                     float *bary, long *stats /*[2]: candidates, fragments*/) {
+                                     float *bary, long *stats /*[4]: candidates, fragments, max candidates per tile, max chunk hits per tile*/) {
     const int is = S * ssaa;
     Cam cam{K[0], K[1], K[2], K[3], K[4], K[5], orig_size};
     const bool implicit = faces == nullptr;
     const int nblk = (S - 1 + 7) / 8;
     const int nchunks = implicit ? nblk * nblk : (F + 63) / 64;
     std::vector<float> dss((size_t)is * is);
-    stats[0] = stats[1] = 0;
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
     for (int b = 0; b < B; b++) {
         std::vector<P4> proj(N);
         for (int i = 0; i < N; i++) {
@@ -72,10 +72,12 @@ extern "C" int g2s_emul_render_depth(const float *verts, const int *faces, int B
                 const float txlo = sample_centre(tx * 8, is), txhi = sample_centre(xl, is);
                 const float tylo = sample_centre(ty * 8, is), tyhi = sample_centre(yl, is);
                 std::vector<FaceRec> list;
+                long chunk_hits = 0;
                 for (int c = 0; c < nchunks; c++) {
                     if (!bbox_overlaps(cbox[c].xmin, cbox[c].ymin, cbox[c].xmax, cbox[c].ymax, txlo,
                                        tylo, txhi, tyhi))
                         continue;
+                    chunk_hits++;
                     for (int g : cfaces[c]) {
                         int v[3];
                         if (implicit) implicit_face(g, S, v);
@@ -85,13 +87,17 @@ extern "C" int g2s_emul_render_depth(const float *verts, const int *faces, int B
                         grow(bb, p0); grow(bb, p1); grow(bb, p2);
                         if (!bbox_overlaps(bb.xmin, bb.ymin, bb.xmax, bb.ymax, txlo, tylo, txhi, tyhi))
                             continue;
-                        if (!back_facing(p0.x, p0.y, p1.x, p1.y, p2.x, p2.y))
+                        if (!back_facing(p0.x, p0.y, p1.x, p1.y, p2.x, p2.y) &&
+                            tile_may_cover(p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, txlo, tylo, txhi, tyhi))
                             list.push_back(make_rec(p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, g));
-                        if (fill_back && !back_facing(p2.x, p2.y, p1.x, p1.y, p0.x, p0.y))
+                        if (fill_back && !back_facing(p2.x, p2.y, p1.x, p1.y, p0.x, p0.y) &&
+                            tile_may_cover(p2.x, p2.y, p1.x, p1.y, p0.x, p0.y, txlo, tylo, txhi, tyhi))
                             list.push_back(make_rec(p2.x, p2.y, p2.z, p1.x, p1.y, p1.z, p0.x, p0.y, p0.z, g + F));
                     }
                 }
                 stats[0] += (long)list.size();
+                if ((long)list.size() > stats[2]) stats[2] = (long)list.size();
+                if (chunk_hits > stats[3]) stats[3] = chunk_hits;
                 for (int l = 0; l < 64; l++) {
                     const int xi = tx * 8 + (l & 7), yi = ty * 8 + (l >> 3);
                     if (xi >= is || yi >= is) continue;

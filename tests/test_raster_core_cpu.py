@@ -43,13 +43,14 @@ def run_emul(lib, verts, faces, S, K, ssaa, fill_back, near=0.1, far=FAR, implic
     depth = np.empty((B, S, S), np.float32)
     fidx = np.empty((B, isz, isz), np.int32)
     bary = np.empty((B, isz, isz, 3), np.float32)
-    stats = (C.c_long * 2)()
+    stats = (C.c_long * 4)()
     Kf = np.ascontiguousarray(K, np.float32).reshape(9)
     rc = lib.g2s_emul_render_depth(_f(verts), _i(None if implicit else faces), B, N, F, S, _f(Kf),
                                    C.c_float(S), ssaa, int(fill_back), C.c_float(near),
                                    C.c_float(far), _f(depth), _i(fidx), _f(bary), stats)
     assert rc == 0
-    return dict(depth=depth, face_idx=fidx, bary=bary, candidates=stats[0], fragments=stats[1])
+    return dict(depth=depth, face_idx=fidx, bary=bary, candidates=stats[0], fragments=stats[1],
+                max_candidates=stats[2], max_chunks=stats[3])
 
 
 @pytest.mark.parametrize("S,ssaa,fill_back,implicit", [
