@@ -7,17 +7,21 @@
 //
 //   setup   one wavefront per 8x8-quad mesh block (implicit grid topology) or per 64 consecutive
 //           faces (explicit topology): project vertices once, reduce the block's bounding box.
-//   tiles   one wavefront per 8x8-sample tile, 4 tiles (16x16 samples) per workgroup, no barriers:
+//   tiles   one workgroup of 4 wavefronts per 8x8-sample tile (lane = sample); the surviving mesh
+//           blocks are dealt round-robin to the 4 waves, each with its own LDS list and queue, and
+//           the waves meet in one shared per-sample minimum:
 //             1. lanes test chunk boxes against the tile, wave-ballot the survivors;
 //             2. per surviving chunk, lane = quad / face: front-face test + face box test + exact
 //                (conservative) triangle-vs-tile edge test, ballot
 //                + mbcnt compaction of the surviving oriented faces into a per-wave LDS list;
-//             3. lane = sample: walk the list with LDS broadcast reads, three edge inequalities per
-//                face, remember covering faces (up to 8 byte-indices in a 64-bit register);
-//             4. lane = sample: evaluate only the remembered (sample, face) fragments — inverse
-//                vertex matrix, clamped barycentrics, perspective-correct depth — keep the
-//                lexicographic (depth, face id) minimum;
-//             5. epilogue fused: vertical flip + 2x2 average pooling through DPP shuffles.
+//             3. lane = list entry: inverse vertex matrix once per listed face; then lane = sample:
+//                walk the list with LDS broadcast reads, three edge inequalities per face, and
+//                push covering (sample, face) pairs into an LDS ring (ballot + mbcnt);
+//             4. lane = queued fragment, 64 at a time whatever sample they belong to: clamped
+//                barycentrics, perspective-correct depth, near/far; the lexicographic
+//                (depth, face id) minimum per sample is one ds_min_u64 on an order-preserving key;
+//             5. epilogue fused: winner's weights recomputed once, vertical flip + 2x2 average
+//                pooling through shuffles.
 //           ~70 candidate faces per tile instead of 64 516.
 //   bwd     one thread per raster sample: analytic gradient to the three projected vertices with
 //           float atomics, then one thread per vertex for the projection backward.
@@ -27,13 +31,14 @@
 #include "g2s_common.h"
 #include "raster_core.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace g2s {
 
 constexpr int TILE = 8;      // samples per tile side (64 samples = one wavefront)
-constexpr int CAP = 128;     // LDS face-list capacity per wavefront
-constexpr int WAVES = 4;     // wavefronts (tiles) per workgroup
-constexpr int MAXH = 8;      // covering faces remembered per sample before evaluation
+constexpr int CAP = 64;      // LDS face-list capacity per wavefront
+constexpr int QCAP = 128;    // fragment queue ring (drained at 64, refilled by at most 64)
+constexpr int WAVES = 4;     // wavefronts per workgroup, all working on one tile
 
 struct RasterParams {
     const float *verts;
@@ -118,138 +123,232 @@ __global__ __launch_bounds__(64) void raster_chunk_boxes(RasterParams p) {
 }
 
 // ---------------------------------------------------------------------------------- tiles
-struct Lists {  // per-wave LDS face list, structure of float4 arrays (conflict-free lane writes)
-    float4 e0[CAP], e1[CAP], e2[CAP], zf[CAP];
+struct Lists {  // per-wave LDS state, structure of float4 arrays (conflict-free lane writes)
+    float4 e0[CAP], e1[CAP], e2[CAP], zf[CAP];  // coverage edges; vertex depths + face id
+    float4 fa[CAP], fb[CAP];                    // inverse vertex matrix entries 0-3, 4-7
+    float fc[CAP];                              // inverse vertex matrix entry 8
+    unsigned short queue[QCAP];                 // pending fragments: list entry << 6 | sample
 };
 
-struct Sample {  // per-lane state
-    int xi, yi;
-    float xp, yp;
-    bool valid;
-    float best_zp;
-    int best_fn;
-    float w0, w1, w2;
-    unsigned long long hits;
-    int nh;
+struct Tile {  // per-wave state; count/head/qn are wave-uniform
+    int tx, ty, lane;
+    float xp, yp;  // this lane's sample centre
+    bool valid;    // sample inside the raster
+    int count;     // faces in the list
+    int head, qn;  // fragment queue ring: first pending entry, number pending
 };
 
 __device__ __forceinline__ F4 ld4(const float4 &v) { return F4{v.x, v.y, v.z, v.w}; }
 
-// step 4: evaluate the remembered covering faces of every sample.
-__device__ __forceinline__ void eval_hits(const Lists &L, Sample &s, const RasterParams &p) {
-    for (int r = 0; r < MAXH; ++r) {
-        const bool act = s.nh > r;
-        if (!__ballot(act)) break;
-        if (act) {
-            const int e = (int)((s.hits >> (8 * r)) & 0xffull);
-            const float4 a0 = L.e0[e], a1 = L.e1[e], a2 = L.e2[e], a3 = L.zf[e];
-            float fi[9], w[3], zp;
-            face_inverse(a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, p.is, fi);
-            if (fragment(fi, a3.x, a3.y, a3.z, s.xi, s.yi, p.near_, p.far_, w, zp)) {
-                const int fn = __float_as_int(a3.w);
-                if (wins(zp, fn, s.best_zp, s.best_fn)) {
-                    s.best_zp = zp;
-                    s.best_fn = fn;
-                    s.w0 = w[0];
-                    s.w1 = w[1];
-                    s.w2 = w[2];
-                }
-            }
-        }
-    }
-    s.nh = 0;
-    s.hits = 0ull;
+__device__ __forceinline__ int lane_prefix(unsigned long long m) {  // set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// step 3: every sample walks the list (LDS broadcast reads).
-__device__ __forceinline__ void walk_list(const Lists &L, int count, Sample &s,
+// Order-preserving float -> uint map, so that the lexicographic (depth, face id) minimum is one
+// 64-bit integer minimum (ds_min_u64).
+__device__ __forceinline__ unsigned depth_key(float z) {
+    const unsigned u = __float_as_uint(z + 0.0f);  // -0 -> +0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_depth(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// step 4: lane = one pending (sample, face) fragment: clamped barycentrics, perspective-correct
+// depth, near/far rejection, then the packed minimum into the sample's slot.
+__device__ __forceinline__ void eval_queue(Lists &L, unsigned long long *best, const Tile &t, int n,
+                                           const RasterParams &p) {
+    __builtin_amdgcn_wave_barrier();
+    if (t.lane < n) {
+        const unsigned pr = L.queue[(t.head + t.lane) & (QCAP - 1)];
+        const int sl = pr & 63, e = pr >> 6;
+        const float4 fa = L.fa[e], fb = L.fb[e], z = L.zf[e];
+        const float fi[9] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w, L.fc[e]};
+        float w[3], zp;
+        if (fragment(fi, z.x, z.y, z.z, t.tx * TILE + (sl & 7), t.ty * TILE + (sl >> 3), p.near_,
+                     p.far_, w, zp) &&
+            zp == zp) {
+            const unsigned long long key =
+                ((unsigned long long)depth_key(zp) << 32) | (unsigned)__float_as_int(z.w);
+            atomicMin(&best[sl], key);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// steps 3+4 for the current list: lane = list entry computes the inverse vertex matrix once per
+// face, then lane = sample walks the list (LDS broadcast reads, three edge inequalities per face)
+// and queues its covering faces; the queue is drained 64 fragments at a time.
+__device__ __forceinline__ void walk_list(Lists &L, unsigned long long *best, Tile &t,
                                           const RasterParams &p) {
     __builtin_amdgcn_wave_barrier();
-    for (int e = 0; e < count; ++e) {
-        const F4 a0 = ld4(L.e0[e]), a1 = ld4(L.e1[e]), a2 = ld4(L.e2[e]);
-        const bool in = s.valid && covers(a0, a1, a2, s.xp, s.yp);
-        if (in) {
-            s.hits = (s.hits << 8) | (unsigned long long)e;
-            s.nh++;
-        }
-        if (__ballot(s.nh >= MAXH)) eval_hits(L, s, p);
+    const int count = t.count;
+    if (count == 0) return;
+    if (t.lane < count) {
+        const float4 a0 = L.e0[t.lane], a1 = L.e1[t.lane], a2 = L.e2[t.lane];
+        float fi[9];
+        face_inverse(a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, p.is, fi);
+        L.fa[t.lane] = make_float4(fi[0], fi[1], fi[2], fi[3]);
+        L.fb[t.lane] = make_float4(fi[4], fi[5], fi[6], fi[7]);
+        L.fc[t.lane] = fi[8];
     }
-    eval_hits(L, s, p);  // list indices die with the list
+    __builtin_amdgcn_wave_barrier();
+    F4 a0 = ld4(L.e0[0]), a1 = ld4(L.e1[0]), a2 = ld4(L.e2[0]);
+    for (int e = 0; e < count; ++e) {
+        const int en = e + 1 < CAP ? e + 1 : e;  // next entry (stale data past count is harmless)
+        const F4 n0 = ld4(L.e0[en]), n1 = ld4(L.e1[en]), n2 = ld4(L.e2[en]);
+        const bool in = t.valid && covers(a0, a1, a2, t.xp, t.yp);
+        const unsigned long long m = __ballot(in);
+        if (m) {
+            if (in) L.queue[(t.head + t.qn + lane_prefix(m)) & (QCAP - 1)] = (unsigned short)((e << 6) | t.lane);
+            t.qn += __popcll(m);
+            if (t.qn >= 64) {
+                eval_queue(L, best, t, 64, p);
+                t.head = (t.head + 64) & (QCAP - 1);
+                t.qn -= 64;
+            }
+        }
+        a0 = n0;
+        a1 = n1;
+        a2 = n2;
+    }
+    if (t.qn) {  // list indices die with the list
+        eval_queue(L, best, t, t.qn, p);
+        t.head = (t.head + t.qn) & (QCAP - 1);
+        t.qn = 0;
+    }
+    t.count = 0;
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void append(Lists &L, int &count, bool pass, const FaceRec &r, int lane,
-                                       Sample &s, const RasterParams &p) {
+__device__ __forceinline__ void append(Lists &L, unsigned long long *best, Tile &t, bool pass,
+                                       const FaceRec &r, const RasterParams &p) {
     const unsigned long long m = __ballot(pass);
     if (!m) return;
     const int n = __popcll(m);
-    if (count + n > CAP) {
-        walk_list(L, count, s, p);
-        count = 0;
-    }
-    const int idx = count + __popcll(m & ((1ull << lane) - 1ull));
+    if (t.count + n > CAP) walk_list(L, best, t, p);
+    const int idx = t.count + lane_prefix(m);
     if (pass) {
         L.e0[idx] = make_float4(r.e0.x, r.e0.y, r.e0.z, r.e0.w);
         L.e1[idx] = make_float4(r.e1.x, r.e1.y, r.e1.z, r.e1.w);
         L.e2[idx] = make_float4(r.e2.x, r.e2.y, r.e2.z, r.e2.w);
         L.zf[idx] = make_float4(r.zf.x, r.zf.y, r.zf.z, r.zf.w);
     }
-    count += n;
+    t.count += n;
 }
 
-// One geometric triangle (p0, p1, p2) with id g: box test against the tile, then both orientations.
-__device__ __forceinline__ void bin_triangle(Lists &L, int &count, bool valid, const float4 &p0,
-                                             const float4 &p1, const float4 &p2, int g, int lane,
-                                             float txlo, float tylo, float txhi, float tyhi,
-                                             Sample &s, const RasterParams &p) {
+// One geometric triangle (p0, p1, p2) with id g.  The face (p0, p1, p2) keeps id g; with fill_back
+// its reversed copy (p2, p1, p0) has id g + F.  kernel_2 drops back-facing orientations, so of the
+// two at most one survives unless both "return if backside" tests fail together (zero signed area
+// in fp32) — that case takes the second, wave-uniformly rare, append.
+__device__ __forceinline__ void bin_triangle(Lists &L, unsigned long long *best, Tile &t, bool valid,
+                                             const float4 &p0, const float4 &p1, const float4 &p2,
+                                             int g, float txlo, float tylo, float txhi, float tyhi,
+                                             const RasterParams &p) {
     const float bxmin = fminf(p0.x, fminf(p1.x, p2.x)), bxmax = fmaxf(p0.x, fmaxf(p1.x, p2.x));
     const float bymin = fminf(p0.y, fminf(p1.y, p2.y)), bymax = fmaxf(p0.y, fmaxf(p1.y, p2.y));
     const bool ov = valid && bbox_overlaps(bxmin, bymin, bxmax, bymax, txlo, tylo, txhi, tyhi);
+    const bool fwd = !back_facing(p0.x, p0.y, p1.x, p1.y, p2.x, p2.y);
+    const bool rev = p.fill_back && !back_facing(p2.x, p2.y, p1.x, p1.y, p0.x, p0.y);
     {
-        const bool pass = ov && !back_facing(p0.x, p0.y, p1.x, p1.y, p2.x, p2.y) &&
-                          tile_may_cover(p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, txlo, tylo, txhi, tyhi);
-        append(L, count, pass, make_rec(p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, g),
-               lane, s, p);
+        const float4 a = fwd ? p0 : p2, c = fwd ? p2 : p0;
+        const bool pass = ov && (fwd || rev) &&
+                          tile_may_cover(a.x, a.y, p1.x, p1.y, c.x, c.y, txlo, tylo, txhi, tyhi);
+        append(L, best, t, pass,
+               make_rec(a.x, a.y, a.z, p1.x, p1.y, p1.z, c.x, c.y, c.z, fwd ? g : g + p.F), p);
     }
-    if (p.fill_back) {  // reversed copy: vertex order (p2, p1, p0), id g + F
-        const bool pass = ov && !back_facing(p2.x, p2.y, p1.x, p1.y, p0.x, p0.y) &&
-                          tile_may_cover(p2.x, p2.y, p1.x, p1.y, p0.x, p0.y, txlo, tylo, txhi, tyhi);
-        append(L, count, pass,
-               make_rec(p2.x, p2.y, p2.z, p1.x, p1.y, p1.z, p0.x, p0.y, p0.z, g + p.F), lane, s, p);
+    const bool both = ov && fwd && rev;
+    if (__ballot(both)) {
+        const bool pass = both && tile_may_cover(p2.x, p2.y, p1.x, p1.y, p0.x, p0.y, txlo, tylo, txhi, tyhi);
+        append(L, best, t, pass,
+               make_rec(p2.x, p2.y, p2.z, p1.x, p1.y, p1.z, p0.x, p0.y, p0.z, g + p.F), p);
     }
 }
 
+// Vertices of this lane's quad (implicit: v00, v10, v01, v11) or face (explicit: p0, p1, p2) of chunk cc.
+struct ChunkVerts {
+    float4 v[4];
+    bool valid;
+    int id;
+};
+
 template <bool IMPLICIT>
+__device__ __forceinline__ ChunkVerts load_chunk(const RasterParams &p, const float4 *proj, int cc,
+                                                 int lane) {
+    ChunkVerts c;
+    c.v[0] = c.v[1] = c.v[2] = c.v[3] = make_float4(0, 0, 0, 0);
+    if (IMPLICIT) {
+        const int Sm1 = p.S - 1;
+        const int qi = (cc / p.nblk_side) * 8 + (lane >> 3);
+        const int qj = (cc % p.nblk_side) * 8 + (lane & 7);
+        c.valid = qi < Sm1 && qj < Sm1;
+        c.id = qi * Sm1 + qj;
+        if (c.valid) {
+            c.v[0] = proj[qi * p.S + qj];
+            c.v[1] = proj[(qi + 1) * p.S + qj];
+            c.v[2] = proj[qi * p.S + qj + 1];
+            c.v[3] = proj[(qi + 1) * p.S + qj + 1];
+        }
+    } else {
+        const int f = cc * 64 + lane;
+        c.valid = f < p.F;
+        c.id = f;
+        if (c.valid) {
+            c.v[0] = proj[p.faces[3 * f + 0]];
+            c.v[1] = proj[p.faces[3 * f + 1]];
+            c.v[2] = proj[p.faces[3 * f + 2]];
+        }
+    }
+    return c;
+}
+
+// SPLIT = 4: the workgroup's 4 waves share one tile (few tiles in flight: shortens the longest
+// serial chain); SPLIT = 1: one tile per wave, 2x2 tiles per workgroup (many tiles in flight: no
+// duplicated per-wave prologue).
+template <bool IMPLICIT, int SPLIT>
 __global__ __launch_bounds__(64 * WAVES) void raster_tiles(RasterParams p) {
     __shared__ Lists lists[WAVES];
+    __shared__ unsigned long long bests[WAVES / SPLIT][64];  // per sample: packed (depth key, face id) minimum
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tiles_side = (p.is + TILE - 1) / TILE;
-    const int wg_side = (tiles_side + 1) / 2;
-    const int tx = (blockIdx.x % wg_side) * 2 + (wave & 1);
-    const int ty = (blockIdx.x / wg_side) * 2 + (wave >> 1);
+    Tile t;
+    t.lane = lane;
+    int part;  // this wave's share of the surviving chunks: rank mod SPLIT
+    if (SPLIT == WAVES) {
+        // consecutive workgroup ids go round-robin over the 8 XCDs: give each XCD a contiguous band
+        // of tiles so that neighbouring tiles find the shared mesh blocks in the same L2
+        const int ntiles = tiles_side * tiles_side;
+        int tile = blockIdx.x;
+        if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
+        t.tx = tile % tiles_side;
+        t.ty = tile / tiles_side;
+        part = wave;
+    } else {
+        const int wg_side = (tiles_side + 1) / 2;
+        t.tx = (blockIdx.x % wg_side) * 2 + (wave & 1);
+        t.ty = (blockIdx.x / wg_side) * 2 + (wave >> 1);
+        part = 0;
+        if (t.tx >= tiles_side || t.ty >= tiles_side) return;  // no workgroup barrier in this variant
+    }
     const int b = blockIdx.y;
-    if (tx >= tiles_side || ty >= tiles_side) return;  // no barriers below: a wave may leave alone
     Lists &L = lists[wave];
+    unsigned long long *best = bests[SPLIT == WAVES ? 0 : wave];
 
-    Sample s;
-    s.xi = tx * TILE + (lane & 7);
-    s.yi = ty * TILE + (lane >> 3);
-    s.valid = s.xi < p.is && s.yi < p.is;
-    s.xp = sample_centre(s.xi, p.is);
-    s.yp = sample_centre(s.yi, p.is);
-    s.best_zp = p.far_;
-    s.best_fn = INT_MAX;
-    s.w0 = s.w1 = s.w2 = 0.0f;
-    s.hits = 0ull;
-    s.nh = 0;
+    const int xi = t.tx * TILE + (lane & 7), yi = t.ty * TILE + (lane >> 3);
+    t.valid = xi < p.is && yi < p.is;
+    t.xp = sample_centre(xi, p.is);
+    t.yp = sample_centre(yi, p.is);
+    t.count = t.head = t.qn = 0;
+    if (part == 0) best[lane] = ((unsigned long long)depth_key(p.far_) << 32) | (unsigned)INT_MAX;
+    if (SPLIT == WAVES) __syncthreads();
 
-    const int x_last = min(tx * TILE + TILE - 1, p.is - 1), y_last = min(ty * TILE + TILE - 1, p.is - 1);
-    const float txlo = sample_centre(tx * TILE, p.is), txhi = sample_centre(x_last, p.is);
-    const float tylo = sample_centre(ty * TILE, p.is), tyhi = sample_centre(y_last, p.is);
+    const int x_last = min(t.tx * TILE + TILE - 1, p.is - 1), y_last = min(t.ty * TILE + TILE - 1, p.is - 1);
+    const float txlo = sample_centre(t.tx * TILE, p.is), txhi = sample_centre(x_last, p.is);
+    const float tylo = sample_centre(t.ty * TILE, p.is), tyhi = sample_centre(y_last, p.is);
 
     const float4 *bb = p.chunkbb + (size_t)b * p.nchunks;
     const float4 *proj = p.proj + (size_t)b * p.N;
-    int count = 0;
+    int rank = 0;  // running index of surviving chunks: chunk k belongs to the wave with part == k mod SPLIT
     for (int c0 = 0; c0 < p.nchunks; c0 += 64) {
         const int c = c0 + lane;
         bool hit = false;
@@ -257,60 +356,95 @@ __global__ __launch_bounds__(64 * WAVES) void raster_tiles(RasterParams p) {
             const float4 q = bb[c];
             hit = bbox_overlaps(q.x, q.y, q.z, q.w, txlo, tylo, txhi, tyhi);
         }
-        unsigned long long mask = __ballot(hit);
-        while (mask) {
-            const int cc = c0 + __builtin_ctzll(mask);
-            mask &= mask - 1ull;
+        const unsigned long long all = __ballot(hit);
+        // keep the bits whose rank (rank + number of lower set bits) is congruent to this wave
+        unsigned long long mask = all;
+        if (SPLIT > 1) {
+            mask = 0ull;
+            unsigned long long m = all;
+            int k = rank;
+            while (m) {
+                const unsigned long long low = m & (0ull - m);
+                if ((k & (SPLIT - 1)) == part) mask |= low;
+                m ^= low;
+                ++k;
+            }
+            rank = k;
+        }
+        if (!mask) continue;
+        // the vertices of the next surviving chunk are requested before the current one is binned
+        ChunkVerts cur = load_chunk<IMPLICIT>(p, proj, c0 + __builtin_ctzll(mask), lane);
+        mask &= mask - 1ull;
+        while (true) {
+            const bool more = mask != 0ull;
+            ChunkVerts nxt = cur;
+            if (more) {
+                nxt = load_chunk<IMPLICIT>(p, proj, c0 + __builtin_ctzll(mask), lane);
+                mask &= mask - 1ull;
+            }
             if (IMPLICIT) {
                 const int Sm1 = p.S - 1;
-                const int qi = (cc / p.nblk_side) * 8 + (lane >> 3);
-                const int qj = (cc % p.nblk_side) * 8 + (lane & 7);
-                const bool valid = qi < Sm1 && qj < Sm1;
-                float4 v00 = make_float4(0, 0, 0, 0), v10 = v00, v01 = v00, v11 = v00;
-                if (valid) {
-                    v00 = proj[qi * p.S + qj];
-                    v10 = proj[(qi + 1) * p.S + qj];
-                    v01 = proj[qi * p.S + qj + 1];
-                    v11 = proj[(qi + 1) * p.S + qj + 1];
-                }
-                const int q = qi * Sm1 + qj;
-                bin_triangle(L, count, valid, v00, v10, v01, q, lane, txlo, tylo, txhi, tyhi, s, p);
-                bin_triangle(L, count, valid, v01, v10, v11, Sm1 * Sm1 + q, lane, txlo, tylo, txhi,
-                             tyhi, s, p);
+                bin_triangle(L, best, t, cur.valid, cur.v[0], cur.v[1], cur.v[2], cur.id, txlo, tylo,
+                             txhi, tyhi, p);
+                bin_triangle(L, best, t, cur.valid, cur.v[2], cur.v[1], cur.v[3], Sm1 * Sm1 + cur.id,
+                             txlo, tylo, txhi, tyhi, p);
             } else {
-                const int f = cc * 64 + lane;
-                const bool valid = f < p.F;
-                float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
-                if (valid) {
-                    p0 = proj[p.faces[3 * f + 0]];
-                    p1 = proj[p.faces[3 * f + 1]];
-                    p2 = proj[p.faces[3 * f + 2]];
-                }
-                bin_triangle(L, count, valid, p0, p1, p2, f, lane, txlo, tylo, txhi, tyhi, s, p);
+                bin_triangle(L, best, t, cur.valid, cur.v[0], cur.v[1], cur.v[2], cur.id, txlo, tylo,
+                             txhi, tyhi, p);
             }
+            if (!more) break;
+            cur = nxt;
         }
     }
-    walk_list(L, count, s, p);
+    walk_list(L, best, t, p);
+    if (SPLIT == WAVES) {
+        __syncthreads();
+        if (part != 0) return;
+    }
 
     // ---- epilogue: saved maps (unflipped raster), flip + average pooling
-    const bool bg = s.best_fn == INT_MAX;
-    const float d = bg ? p.far_ : s.best_zp;
-    if (p.face_idx && s.valid) {
-        const size_t si = ((size_t)b * p.is + s.yi) * p.is + s.xi;
-        p.face_idx[si] = bg ? -1 : s.best_fn;
-        p.bary[3 * si + 0] = s.w0;
-        p.bary[3 * si + 1] = s.w1;
-        p.bary[3 * si + 2] = s.w2;
+    const unsigned long long win = best[lane];
+    const int best_fn = (int)(unsigned)(win & 0xffffffffull);
+    const bool bg = best_fn == INT_MAX;
+    const float d = bg ? p.far_ : key_depth((unsigned)(win >> 32));
+    if (p.face_idx && t.valid) {
+        // weights of the winning fragment: same arithmetic on the same inputs as when it was queued
+        float w[3] = {0.0f, 0.0f, 0.0f};
+        if (!bg) {
+            int v[3];
+            const int g = best_fn % p.F;
+            if (IMPLICIT) {
+                implicit_face(g, p.S, v);
+            } else {
+                v[0] = p.faces[3 * g];
+                v[1] = p.faces[3 * g + 1];
+                v[2] = p.faces[3 * g + 2];
+            }
+            if (best_fn >= p.F) {
+                const int tmp = v[0];
+                v[0] = v[2];
+                v[2] = tmp;
+            }
+            const float4 q0 = proj[v[0]], q1 = proj[v[1]], q2 = proj[v[2]];
+            float fi[9], zp;
+            face_inverse(q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, p.is, fi);
+            fragment(fi, q0.z, q1.z, q2.z, xi, yi, p.near_, p.far_, w, zp);
+        }
+        const size_t si = ((size_t)b * p.is + yi) * p.is + xi;
+        p.face_idx[si] = bg ? -1 : best_fn;
+        p.bary[3 * si + 0] = w[0];
+        p.bary[3 * si + 1] = w[1];
+        p.bary[3 * si + 2] = w[2];
     }
     if (p.ssaa == 2) {
         const float d_r = __shfl_down(d, 1), d_u = __shfl_down(d, 8), d_ur = __shfl_down(d, 9);
-        if (s.valid && !(lane & 1) && !((lane >> 3) & 1)) {
+        if (t.valid && !(lane & 1) && !((lane >> 3) & 1)) {
             // flipped row 2r = raster row yi+1 (upper), flipped row 2r+1 = raster row yi
             const float sum = ((d_u + d_ur) + d) + d_r;
-            p.depth_out[((size_t)b * p.S + (p.S - 1 - s.yi / 2)) * p.S + s.xi / 2] = sum / 4.0f;
+            p.depth_out[((size_t)b * p.S + (p.S - 1 - yi / 2)) * p.S + xi / 2] = sum / 4.0f;
         }
-    } else if (s.valid) {
-        p.depth_out[((size_t)b * p.S + (p.S - 1 - s.yi)) * p.S + s.xi] = d;
+    } else if (t.valid) {
+        p.depth_out[((size_t)b * p.S + (p.S - 1 - yi)) * p.S + xi] = d;
     }
 }
 
@@ -449,18 +583,24 @@ extern "C" int g2s_raster_depth_fwd(const float *verts, const int32_t *faces, in
     p.chunkbb = p.proj + (size_t)B * n_verts;
     hipStream_t st = as_stream(stream);
     const int tiles_side = (p.is + TILE - 1) / TILE;
-    const int wg_side = (tiles_side + 1) / 2;
+    const int ntiles = tiles_side * tiles_side, wg_side = (tiles_side + 1) / 2;
+    // few tiles: all 4 waves of a workgroup on one tile; many tiles: one tile per wave
+    static const char *force = getenv("G2S_RASTER_SPLIT");
+    const bool split = force ? atoi(force) == 4 : (long)ntiles * B <= 4096;
+    const dim3 grid = split ? dim3(ntiles, B) : dim3(wg_side * wg_side, B);
     if (!faces) {
         p.nblk_side = implicit_blocks(S);
         p.nchunks = p.nblk_side * p.nblk_side;
         raster_setup_implicit<<<dim3(p.nchunks, B), 64, 0, st>>>(p);
-        raster_tiles<true><<<dim3(wg_side * wg_side, B), 64 * WAVES, 0, st>>>(p);
+        if (split) raster_tiles<true, WAVES><<<grid, 64 * WAVES, 0, st>>>(p);
+        else raster_tiles<true, 1><<<grid, 64 * WAVES, 0, st>>>(p);
     } else {
         p.nblk_side = 0;
         p.nchunks = (n_faces + 63) / 64;
         raster_project<<<cdiv((long)B * n_verts, 256), 256, 0, st>>>(p);
         raster_chunk_boxes<<<dim3(p.nchunks, B), 64, 0, st>>>(p);
-        raster_tiles<false><<<dim3(wg_side * wg_side, B), 64 * WAVES, 0, st>>>(p);
+        if (split) raster_tiles<false, WAVES><<<grid, 64 * WAVES, 0, st>>>(p);
+        else raster_tiles<false, 1><<<grid, 64 * WAVES, 0, st>>>(p);
     }
     return check_launch("g2s_raster_depth_fwd");
 }
