@@ -229,12 +229,21 @@ def main():
     # between the nodes of a replayed graph, so the same launches are timed in an eager pass of
     # one 20-step cycle right after the timed region (same process, same shapes, same kernels).
     mc.PROFILE = [] if args.eager else None
+    # G2S_BENCH_MARK=1 (profiling runs only): a kernel no training step uses brackets the timed
+    # region in a rocprofv3 kernel trace (tools/window_trace.py keeps what lies between the two)
+    mark = torch.ones(3, dtype=torch.int32, device=device) if os.environ.get("G2S_BENCH_MARK") else None
     barrier()
+    if mark is not None:
+        mark.bitwise_not()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         runner.run(PATTERN[i % len(PATTERN)])
     barrier()
     elapsed = time.perf_counter() - t0
+    if mark is not None:
+        mark.bitwise_not()
+        torch.cuda.synchronize()
     # per-kind times (report only): a few iterations of each kind, outside the timed region —
     # recording events between graph launches costs ~1 ms per iteration
     for kind in sorted(set(PATTERN)):

@@ -348,6 +348,24 @@ static int pack(int dy, int dx, int wt) { return (dy + 8) | ((dx + 8) << 8) | (w
 
 using namespace g2s;
 
+// Measured (tile, split-K) choices for the call signatures of the north-star workload.
+struct TunedConv { int B, Cin, Cout, H, k, mode, transpose, fused, tile, splitk; };
+static const TunedConv kTuned[] = {
+#include "modconv_tuned.inc"
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+
+// g2s_modconv_tune: per-thread override of the tile / split-K heuristic (tools/tune_modconv.py).
+static thread_local int g_force_tile = -1, g_force_splitk = -1;
+
+extern "C" int g2s_modconv_tune(int tile, int splitk) {
+    G2S_REQUIRE(tile >= -2 && tile <= 2 && splitk >= -1 && splitk <= 64 && splitk != 0,
+                "tile must be -1 (built-in), -2 (heuristic without the tuned table) or 0..2, "
+                "splitk -1 (built-in) or 1..64");
+    g_force_tile = tile;
+    g_force_splitk = splitk;
+    return G2S_OK;
+}
+
 static int modconv_launch(const float *x, const float *w, const float *in_scale,
                           const float *out_scale, const float *bias, int act, float act_alpha,
                           float act_gain, float *y, int B, int Cin, int Cout, int H, int W, int k,
@@ -439,10 +457,23 @@ static int modconv_launch(const float *x, const float *w, const float *in_scale,
         const long blocks = (long)cdiv(d.M, cfgs[i][0]) * cdiv(nmax, cfgs[i][1]) * d.ncls;
         if (d.M > cfgs[i][0] / 2 && blocks >= 512) { pick = i; break; }
     }
+    int tuned_splitk = -1;
+    if (H == W && g_force_tile != -2)
+        for (const TunedConv *t = kTuned; t->B; ++t)
+            if (t->B == B && t->Cin == Cin && t->Cout == Cout && t->H == H && t->k == k && t->mode == mode &&
+                t->transpose == transpose && t->fused == (bias != nullptr || act != 0)) {
+                pick = t->tile;
+                tuned_splitk = t->splitk;
+                break;
+            }
+    if (g_force_tile >= 0) pick = g_force_tile;
     const int BMv = cfgs[pick][0], BNv = cfgs[pick][1];
     const int tiles = cdiv(d.M, BMv) * cdiv(nmax, BNv);
     int splitk = 1;
     while ((long)tiles * d.ncls * splitk < 512 && kt_min / (splitk * 2) >= 8 && splitk < 64) splitk *= 2;
+    if (tuned_splitk > 0) splitk = tuned_splitk;
+    if (g_force_splitk > 0) splitk = g_force_splitk;
+    splitk = std::max(1, std::min(splitk, kt_min));
     // A bias / activation epilogue needs the complete sum: with split-K it runs as a second,
     // elementwise launch (g2s_fused_bias_act in place) after the partial sums have been added.
     const bool deferred_epilogue = splitk > 1 && (bias != nullptr || act != 0);

@@ -108,6 +108,11 @@ class GAN2Shape(nn.Module):
 
         self._depth_border = None
         self._centers = None
+        # run the independent D / A / V / L nets as concurrent stream branches (see _fork); off by
+        # default: measured slower on MI355X (step 1: 3.45 -> 5.66 ms) — a forked HIP graph pays
+        # more for its cross-queue joins than the overlapped launch latencies give back
+        self.parallel_nets = bool(config.get('parallel_nets', False))
+        self._side_streams = []
 
     # ------------------------------------------------------------------ small helpers
     def rescale_depth(self, depth):
@@ -170,32 +175,54 @@ class GAN2Shape(nn.Module):
     def _no_grad_if(self, cond):
         return torch.no_grad() if cond else torch.enable_grad()
 
+    def _fork(self, jobs):
+        """Run independent sub-networks concurrently: job 0 on the current stream, the others on side
+        streams forked from it and joined before returning.  The D / A / V / L nets are chains of
+        small launch-latency-bound kernels; as parallel branches (of the captured HIP graph, or of
+        the eager stream set) their latencies overlap.  autograd replays each branch's backward on
+        the stream of its forward, so the backward passes overlap too.  Results are identical:
+        only the order in which independent kernels reach the GPU changes."""
+        if len(jobs) < 2 or not self.parallel_nets or self.device.type != 'cuda':
+            return [job() for job in jobs]
+        main = torch.cuda.current_stream(self.device)
+        while len(self._side_streams) < len(jobs) - 1:
+            self._side_streams.append(torch.cuda.Stream(self.device))
+        outs = [None] * len(jobs)
+        for i, (job, side) in enumerate(zip(jobs[1:], self._side_streams), 1):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                outs[i] = job()
+        outs[0] = jobs[0]()
+        for out, side in zip(outs[1:], self._side_streams):
+            main.wait_stream(side)
+            out.record_stream(main)
+        return outs
+
     # ------------------------------------------------------------------ step 1
     def forward_step1(self, images, latents, collected, step1=True, eval=False, **kwargs):
         """model.py:95-173: optimise the albedo net (step1=True) / everything (step1=False).
 
-        `_view_light`, `_defer_perc` are internal (forward_step3 batches the image with its projected
+        `_nets`, `_defer_perc` are internal (forward_step3 batches the image with its projected
         samples through V / L and through LPIPS; the arithmetic per sample is unchanged)."""
         b = 1
         h, w = self.image_size, self.image_size
-        with self._no_grad_if(step1):
-            depth_raw = self.depth_net(images)
-        depth = self.get_clamped_depth(depth_raw.squeeze(1), h, w)
-        pre = kwargs.get('_view_light')
-        if pre is None:
-            with self._no_grad_if(step1):
-                view = self.viewpoint_net(images)
+
+        def frozen_if_step1(net, x):  # model.py:99-122: only the albedo net learns in step 1
+            def job():
+                with self._no_grad_if(step1):
+                    return net(x)
+            return job
+
+        pre = kwargs.get('_nets')
+        if pre is None:  # the four nets read the same image and nothing else: independent chains
+            depth_raw, albedo, view, lighting = self._fork([
+                frozen_if_step1(self.depth_net, images), lambda: self.albedo_net(images),
+                frozen_if_step1(self.viewpoint_net, images), frozen_if_step1(self.lighting_net, images)])
         else:
-            view = pre[0]
+            depth_raw, albedo, view, lighting = pre
+        depth = self.get_clamped_depth(depth_raw.squeeze(1), h, w)
         view = view + self.view_light_sampler.view_mean.unsqueeze(0)
         self._set_view(view)
-
-        albedo = self.albedo_net(images)
-        if pre is None:
-            with self._no_grad_if(step1):
-                lighting = self.lighting_net(images)
-        else:
-            lighting = pre[1]
         lighting = lighting + self.view_light_sampler.light_mean.unsqueeze(0)
 
         normal = self.renderer.get_normal_from_depth(depth)
@@ -261,9 +288,13 @@ class GAN2Shape(nn.Module):
 
     def latent_projection(self, image, gan_im, latent, center_w, center_h, F1_d):
         """model.py:282-289."""
-        offset = self.offset_encoder_net(image)
         if self.relative_encoding:
-            offset = offset - self.offset_encoder_net(gan_im)
+            # one pass of E over the samples and the GAN image together (the encoder has no batch
+            # statistics: per-sample results equal the reference's two calls, launches halve)
+            both = self.offset_encoder_net(torch.cat([image, gan_im], 0))
+            offset = both[:len(image)] - both[len(image):]
+        else:
+            offset = self.offset_encoder_net(image)
         hidden = offset + center_h
         offset = self.generator.style_forward(hidden, skip=8 - F1_d) - center_w
         return offset, latent + offset
@@ -314,11 +345,12 @@ class GAN2Shape(nn.Module):
         b = len(projected_samples)
         both = torch.cat([images[:1], projected_samples], 0) if len(images) == 1 else None
         if both is not None:
-            view_all = self.viewpoint_net(both)
-            light_all = self.lighting_net(both)
+            depth_raw, albedo1, view_all, light_all = self._fork([
+                lambda: self.depth_net(images), lambda: self.albedo_net(images),
+                lambda: self.viewpoint_net(both), lambda: self.lighting_net(both)])
             step1_loss, collected, perc1 = self.forward_step1(
-                images, None, None, step1=False, _view_light=(view_all[:1], light_all[:1]),
-                _defer_perc=True)
+                images, None, None, step1=False,
+                _nets=(depth_raw, albedo1, view_all[:1], light_all[:1]), _defer_perc=True)
             view, light = view_all[1:], light_all[1:]
         else:
             step1_loss, collected = self.forward_step1(images, None, None, step1=False)

@@ -36,6 +36,19 @@ class UpFirDn2dBackward(Function):
         return gradgrad_out, None, None, None, None, None, None, None, None
 
 
+_FLIPPED = {}  # (data_ptr, version, shape) -> flipped FIR kernel: constant buffers, flipped once
+
+
+def _flipped(kernel):
+    key = (kernel.data_ptr(), kernel._version, tuple(kernel.shape), kernel.device)
+    hit = _FLIPPED.get(key)
+    if hit is None:
+        if len(_FLIPPED) > 64:
+            _FLIPPED.clear()
+        hit = _FLIPPED[key] = (kernel, torch.flip(kernel, [0, 1]))  # holds `kernel`: the ptr stays unique
+    return hit[1]
+
+
 class UpFirDn2d(Function):
     """upfirdn2d.py:87-141."""
 
@@ -48,7 +61,7 @@ class UpFirDn2d(Function):
         batch, channel, in_h, in_w = input.shape
         ctx.in_size = input.shape
         input = input.reshape(-1, in_h, in_w, 1)
-        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
+        ctx.save_for_backward(kernel, _flipped(kernel))
         out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h) // down_y + 1
         out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w) // down_x + 1
         ctx.out_size = (out_h, out_w)

@@ -72,16 +72,17 @@ class Downsample(nn.Module):
 class Blur(nn.Module):
     """model.py:75-91."""
 
-    def __init__(self, kernel, pad, upsample_factor=1):
+    def __init__(self, kernel, pad, upsample_factor=1, down=1):
         super().__init__()
         kernel = make_kernel(kernel)
         if upsample_factor > 1:
             kernel = kernel * (upsample_factor ** 2)
         self.register_buffer('kernel', kernel)
         self.pad = pad
+        self.down = down  # > 1: only every down-th output is computed (see ConvLayer)
 
     def forward(self, input):
-        return upfirdn2d(input, self.kernel, pad=self.pad)
+        return upfirdn2d(input, self.kernel, down=self.down, pad=self.pad)
 
 
 class _ScaledWeight:
@@ -413,15 +414,18 @@ class Generator(nn.Module):
             latent = self.strided_style(torch.stack(styles, dim=1))
 
         out = self.input(latent)
-        out = self.conv1(out, latent[:, 0], noise=noise[0])
-        skip = self.to_rgb1(out, latent[:, 1])
+        # one unbind instead of 2 * n_latent selects: the backward is a single stack, not a
+        # zero-fill + copy + add per use (model.py:493-503 indexes latent[:, i] per layer)
+        lat = latent.unbind(1)
+        out = self.conv1(out, lat[0], noise=noise[0])
+        skip = self.to_rgb1(out, lat[1])
         i = 1
         features = []
         for conv1, conv2, noise1, noise2, to_rgb in zip(self.convs[::2], self.convs[1::2],
                                                         noise[1::2], noise[2::2], self.to_rgbs):
-            out = conv1(out, latent[:, i], noise=noise1)
-            out = conv2(out, latent[:, i + 1], noise=noise2)
-            skip = to_rgb(out, latent[:, i + 2], skip)
+            out = conv1(out, lat[i], noise=noise1)
+            out = conv2(out, lat[i + 1], noise=noise2)
+            skip = to_rgb(out, lat[i + 2], skip)
             features.append(out)
             i += 2
         image = skip
@@ -441,8 +445,12 @@ class ConvLayer(nn.Sequential):
         if downsample:
             factor = 2
             p = (len(blur_kernel) - factor) + (kernel_size - 1)
-            layers.append(Blur(blur_kernel, pad=((p + 1) // 2, p // 2)))
-            stride = 2
+            # A 1x1 stride-2 convolution reads every other blurred pixel only: the blur computes
+            # just those (upfirdn2d down=2, a quarter of the work) and the convolution runs at
+            # stride 1 on the contiguous result — same values as blur + strided conv (model.py:650-668).
+            point = kernel_size == 1
+            layers.append(Blur(blur_kernel, pad=((p + 1) // 2, p // 2), down=2 if point else 1))
+            stride = 1 if point else 2
             self.padding = 0
         else:
             stride = 1

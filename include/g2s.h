@@ -150,6 +150,13 @@ int g2s_conv_bias_act(const float *x, const float *w, const float *bias, float *
                       int Cout, int H, int W, int k, int mode, int act, float alpha, float gain,
                       g2s_stream_t stream);
 
+/* Tuning hook (tools/tune_modconv.py): force the tile configuration (0: 128x128, 1: 128x64,
+ * 2: 64x64 output channels x pixels) and/or the split-K factor of the calling thread's following
+ * g2s_modconv / g2s_conv_bias_act launches; -1 restores the built-in choice (measured table
+ * csrc/modconv_tuned.inc, else a heuristic), tile = -2 selects the heuristic alone.  Results do not
+ * depend on the choice beyond the fp32 summation order. */
+int g2s_modconv_tune(int tile, int splitk);
+
 /* ------------------------------------------------------------------------------------------
  * Row-wise fused reductions around the modulated convolution (csrc/rowops.hip).
  * g2s_rows_dot_scale: a, b, out are [rows, n] f32; s, inv, dot are [rows].
