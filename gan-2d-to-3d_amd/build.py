@@ -25,6 +25,7 @@ SOURCES = {
     "rowops.hip": [],
     "lpips.hip": [],
     "geometry.hip": ["-ffp-contract=off"],
+    "groupnorm.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

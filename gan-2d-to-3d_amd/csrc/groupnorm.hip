@@ -1,0 +1,282 @@
+// groupnorm.hip — GroupNorm + (leaky-)ReLU of the depth / albedo nets as two launches per direction,
+// behind g2s_groupnorm_act_fwd / _bwd (include/g2s.h).
+//
+// The EncoderDecoder nets (GAN2Shape/networks.py:79-141) put nn.GroupNorm + nn.ReLU / nn.LeakyReLU
+// after 11 of their convolutions and run at batch 1: PyTorch spends 4 launches forward and 5
+// backward per pair, the moments kernel with one workgroup per group (8-32 workgroups on a
+// 256-CU chip).  Here:
+//
+//   fwd   stats  : grid (slices, B*G): every 4096-element slice of a group reduces to
+//                  (count, mean, M2) exactly in registers (two passes over values held in VGPRs);
+//         apply  : thread = float4: combines its group's slices (Chan's parallel formula),
+//                  y = act((x - mean) * rstd * gamma + beta); saves mean / rstd.
+//   bwd   sums   : workgroup = (b, c): s1 = sum g, s2 = sum g * xhat, g = gy * act'(y);
+//         apply  : thread = float4: group sums from its channels' (s1, s2),
+//                  dx = rstd * (g*gamma - (ds*xhat + db) / n); the threads that own the first
+//                  float4 of a channel in batch 0 also write dgamma / dbeta (sum over the batch).
+//
+// No atomics: results are deterministic.
+#include "g2s_common.h"
+
+namespace g2s {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_SLICE = 4096;  // elements per stats workgroup: 4 float4 per thread
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// sum over the 256 threads of a workgroup; every thread gets the result
+__device__ __forceinline__ float block_sum(float v, float *sm) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+struct GnParams {
+    const float *x, *gamma, *beta;
+    float *y, *mean, *rstd, *part;  // part [B*G, S, 3] = (count, mean, M2)
+    int B, C, HW, G, S;
+    int n;                          // elements per group = C/G * HW
+    float eps;
+    int act;                        // 0: none, 1: leaky-ReLU(alpha) (alpha = 0: ReLU)
+    float alpha;
+};
+
+__global__ __launch_bounds__(GN_THREADS) void gn_stats(GnParams p) {
+    __shared__ float sm[4];
+    const int s = blockIdx.x, bg = blockIdx.y;
+    const float4 *x4 = reinterpret_cast<const float4 *>(p.x + (size_t)bg * p.n);
+    const int n4 = p.n >> 2, base = s * (GN_SLICE / 4);
+    float4 v[4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int i = base + e * GN_THREADS + threadIdx.x;
+        const bool ok = i < n4;
+        v[e] = ok ? x4[i] : make_float4(0, 0, 0, 0);
+        sum += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+    }
+    const int total = min(GN_SLICE, p.n - s * GN_SLICE);
+    const float mean = block_sum(sum, sm) / (float)total;
+    float m2 = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (base + e * GN_THREADS + threadIdx.x < n4) {
+            const float a = v[e].x - mean, b = v[e].y - mean, c = v[e].z - mean, d = v[e].w - mean;
+            m2 += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    m2 = block_sum(m2, sm);
+    if (threadIdx.x == 0) {
+        float *o = p.part + ((size_t)bg * p.S + s) * 3;
+        o[0] = (float)total;
+        o[1] = mean;
+        o[2] = m2;
+    }
+}
+
+// Chan et al.: merge (count, mean, M2) partials in slice order.
+__device__ __forceinline__ void gn_group_stats(const float *part, int S, float eps, float &mean,
+                                               float &rstd) {
+    float n = part[0], m = part[1], m2 = part[2];
+    for (int s = 1; s < S; s++) {
+        const float nb = part[3 * s], mb = part[3 * s + 1], m2b = part[3 * s + 2];
+        const float d = mb - m, nt = n + nb;
+        m += d * (nb / nt);
+        m2 += m2b + d * d * (n * nb / nt);
+        n = nt;
+    }
+    mean = m;
+    rstd = rsqrtf(m2 / n + eps);
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply(GnParams p) {
+    const long i4 = (long)blockIdx.x * GN_THREADS + threadIdx.x;
+    const long total4 = (long)p.B * p.C * p.HW / 4;
+    if (i4 >= total4) return;
+    const long e = i4 * 4;
+    const int bc = (int)(e / p.HW), c = bc % p.C, b = bc / p.C;
+    const int cpg = p.C / p.G, bg = b * p.G + c / cpg;
+    float mean, rstd;
+    gn_group_stats(p.part + (size_t)bg * p.S * 3, p.S, p.eps, mean, rstd);
+    if (e == (long)bg * p.n) {
+        p.mean[bg] = mean;
+        p.rstd[bg] = rstd;
+    }
+    const float ga = p.gamma[c] * rstd, be = p.beta[c] - mean * ga;
+    float4 v = reinterpret_cast<const float4 *>(p.x)[i4];
+    v.x = v.x * ga + be;
+    v.y = v.y * ga + be;
+    v.z = v.z * ga + be;
+    v.w = v.w * ga + be;
+    if (p.act) {
+        v.x = v.x > 0.0f ? v.x : v.x * p.alpha;
+        v.y = v.y > 0.0f ? v.y : v.y * p.alpha;
+        v.z = v.z > 0.0f ? v.z : v.z * p.alpha;
+        v.w = v.w > 0.0f ? v.w : v.w * p.alpha;
+    }
+    reinterpret_cast<float4 *>(p.y)[i4] = v;
+}
+
+struct GnBwdParams {
+    const float *gy, *y, *x, *gamma, *mean, *rstd;
+    float *dx, *dgamma, *dbeta, *sums;  // sums [B*C, 2] = (sum g, sum g * xhat)
+    int B, C, HW, G, n;
+    int act;
+    float alpha;
+};
+
+__device__ __forceinline__ float act_grad(float gy, float y, int act, float alpha) {
+    return act ? (y > 0.0f ? gy : gy * alpha) : gy;
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_bwd_sums(GnBwdParams p) {
+    __shared__ float sm[4];
+    const int bc = blockIdx.x, c = bc % p.C, b = bc / p.C;
+    const int bg = b * p.G + c / (p.C / p.G);
+    const float mean = p.mean[bg], rstd = p.rstd[bg];
+    const float4 *gy4 = reinterpret_cast<const float4 *>(p.gy + (size_t)bc * p.HW);
+    const float4 *y4 = reinterpret_cast<const float4 *>(p.y + (size_t)bc * p.HW);
+    const float4 *x4 = reinterpret_cast<const float4 *>(p.x + (size_t)bc * p.HW);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int i = threadIdx.x; i < p.HW / 4; i += GN_THREADS) {
+        const float4 g = gy4[i], yy = y4[i], xx = x4[i];
+        const float g0 = act_grad(g.x, yy.x, p.act, p.alpha), g1 = act_grad(g.y, yy.y, p.act, p.alpha);
+        const float g2 = act_grad(g.z, yy.z, p.act, p.alpha), g3 = act_grad(g.w, yy.w, p.act, p.alpha);
+        s1 += (g0 + g1) + (g2 + g3);
+        s2 += (g0 * (xx.x - mean) + g1 * (xx.y - mean)) + (g2 * (xx.z - mean) + g3 * (xx.w - mean));
+    }
+    s1 = block_sum(s1, sm);
+    s2 = block_sum(s2, sm) * rstd;
+    if (threadIdx.x == 0) {
+        p.sums[2 * bc] = s1;
+        p.sums[2 * bc + 1] = s2;
+    }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_bwd_apply(GnBwdParams p) {
+    const long i4 = (long)blockIdx.x * GN_THREADS + threadIdx.x;
+    const long total4 = (long)p.B * p.C * p.HW / 4;
+    if (i4 >= total4) return;
+    const long e = i4 * 4;
+    const int bc = (int)(e / p.HW), c = bc % p.C, b = bc / p.C;
+    const int cpg = p.C / p.G, g = c / cpg, bg = b * p.G + g;
+    const float mean = p.mean[bg], rstd = p.rstd[bg];
+    float ds = 0.0f, db = 0.0f;  // sum over the group of gamma * (g * xhat), gamma * g
+    for (int k = 0; k < cpg; k++) {
+        const int cc = g * cpg + k;
+        const float ga = p.gamma[cc];
+        db += ga * p.sums[2 * (b * p.C + cc)];
+        ds += ga * p.sums[2 * (b * p.C + cc) + 1];
+    }
+    if (b == 0 && e == (long)c * p.HW) {  // one thread per channel: parameter gradients
+        float dg = 0.0f, dbe = 0.0f;
+        for (int bb = 0; bb < p.B; bb++) {
+            dbe += p.sums[2 * (bb * p.C + c)];
+            dg += p.sums[2 * (bb * p.C + c) + 1];
+        }
+        p.dgamma[c] = dg;
+        p.dbeta[c] = dbe;
+    }
+    const float inv_n = 1.0f / (float)p.n;
+    const float ga = p.gamma[c] * rstd;
+    const float c2 = -ds * inv_n * rstd * rstd;                 // coefficient of (x - mean)
+    const float c3 = -db * inv_n * rstd;
+    const float4 gy = reinterpret_cast<const float4 *>(p.gy)[i4];
+    const float4 yy = reinterpret_cast<const float4 *>(p.y)[i4];
+    const float4 xx = reinterpret_cast<const float4 *>(p.x)[i4];
+    float4 o;
+    o.x = act_grad(gy.x, yy.x, p.act, p.alpha) * ga + ((xx.x - mean) * c2 + c3);
+    o.y = act_grad(gy.y, yy.y, p.act, p.alpha) * ga + ((xx.y - mean) * c2 + c3);
+    o.z = act_grad(gy.z, yy.z, p.act, p.alpha) * ga + ((xx.z - mean) * c2 + c3);
+    o.w = act_grad(gy.w, yy.w, p.act, p.alpha) * ga + ((xx.w - mean) * c2 + c3);
+    reinterpret_cast<float4 *>(p.dx)[i4] = o;
+}
+
+static int gn_check(int B, int C, int HW, int G) {
+    G2S_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0, "sizes must be positive");
+    G2S_REQUIRE(C % G == 0, "channels %d not divisible by groups %d", C, G);
+    G2S_REQUIRE(HW % 4 == 0, "H*W = %d must be a multiple of 4", HW);
+    G2S_REQUIRE((long)B * C * HW < (1l << 31), "tensor too large");
+    return G2S_OK;
+}
+
+}  // namespace g2s
+
+using namespace g2s;
+
+extern "C" size_t g2s_groupnorm_workspace_floats(int B, int C, int HW, int G) {
+    if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) return 0;
+    const long n = (long)(C / G) * HW;
+    const long S = (n + GN_SLICE - 1) / GN_SLICE;
+    const long fwd = (long)B * G * S * 3, bwd = (long)B * C * 2;
+    return (size_t)(fwd > bwd ? fwd : bwd);
+}
+
+extern "C" int g2s_groupnorm_act_fwd(const float *x, const float *gamma, const float *beta, float *y,
+                                     float *mean, float *rstd, float *workspace, int B, int C, int HW,
+                                     int G, float eps, int act, float alpha, g2s_stream_t stream) {
+    G2S_REQUIRE(x && gamma && beta && y && mean && rstd && workspace, "NULL pointer argument");
+    G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
+    int rc = gn_check(B, C, HW, G);
+    if (rc) return rc;
+    GnParams p{};
+    p.x = x;
+    p.gamma = gamma;
+    p.beta = beta;
+    p.y = y;
+    p.mean = mean;
+    p.rstd = rstd;
+    p.part = workspace;
+    p.B = B;
+    p.C = C;
+    p.HW = HW;
+    p.G = G;
+    p.n = C / G * HW;
+    p.S = (p.n + GN_SLICE - 1) / GN_SLICE;
+    p.eps = eps;
+    p.act = act;
+    p.alpha = alpha;
+    hipStream_t st = as_stream(stream);
+    gn_stats<<<dim3(p.S, B * G), GN_THREADS, 0, st>>>(p);
+    gn_apply<<<cdiv((long)B * C * HW / 4, GN_THREADS), GN_THREADS, 0, st>>>(p);
+    return check_launch("g2s_groupnorm_act_fwd");
+}
+
+extern "C" int g2s_groupnorm_act_bwd(const float *gy, const float *y, const float *x,
+                                     const float *gamma, const float *mean, const float *rstd,
+                                     float *dx, float *dgamma, float *dbeta, float *workspace, int B,
+                                     int C, int HW, int G, int act, float alpha, g2s_stream_t stream) {
+    G2S_REQUIRE(gy && y && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace,
+                "NULL pointer argument");
+    G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
+    int rc = gn_check(B, C, HW, G);
+    if (rc) return rc;
+    GnBwdParams p{};
+    p.gy = gy;
+    p.y = y;
+    p.x = x;
+    p.gamma = gamma;
+    p.mean = mean;
+    p.rstd = rstd;
+    p.dx = dx;
+    p.dgamma = dgamma;
+    p.dbeta = dbeta;
+    p.sums = workspace;
+    p.B = B;
+    p.C = C;
+    p.HW = HW;
+    p.G = G;
+    p.n = C / G * HW;
+    p.act = act;
+    p.alpha = alpha;
+    hipStream_t st = as_stream(stream);
+    gn_bwd_sums<<<B * C, GN_THREADS, 0, st>>>(p);
+    gn_bwd_apply<<<cdiv((long)B * C * HW / 4, GN_THREADS), GN_THREADS, 0, st>>>(p);
+    return check_launch("g2s_groupnorm_act_bwd");
+}

@@ -44,6 +44,9 @@ SIGNATURES = {
     "g2s_shading_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "g2s_smooth_loss_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "g2s_smooth_loss_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "g2s_groupnorm_workspace_floats": (_sz, [_i, _i, _i, _i]),
+    "g2s_groupnorm_act_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f, _p]),
+    "g2s_groupnorm_act_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
 }
 
 

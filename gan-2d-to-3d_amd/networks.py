@@ -1,6 +1,7 @@
 """D / A / V / L / E networks of GAN2Shape (arxiv 2011.00844, tables 5-8), state-dict compatible
-with GAN2Shape/networks.py:23-244 (`network.<idx>.weight` keys).  Plain torch.nn on MIOpen — these
-nets are callers inside the step, not custom-kernel targets.
+with GAN2Shape/networks.py:23-244 (`network.<idx>.weight` keys).  Convolutions run as plain torch.nn
+on MIOpen (these nets are callers inside the step); the GroupNorm + activation pairs of the depth /
+albedo nets run as one fused op on the GPU.
 
 PSPNet / BiSeNet / ResNet (networks.py:247-586) only feed the one-shot masking model and are out
 of scope.  The debug gradient alerts (debug_grad_updates.py) are dropped; `debug` is accepted and
@@ -80,7 +81,24 @@ class EncoderDecoder(nn.Module):
         self.network = nn.Sequential(*network)
 
     def forward(self, input):
-        return self.network(input)
+        if not input.is_cuda:
+            return self.network(input)
+        # GPU: every GroupNorm + ReLU / LeakyReLU pair is one op of libg2s.so (2 launches forward,
+        # 2 backward, instead of 4 + 5); the module list — and so the state dict — is unchanged
+        from .op.groupnorm import groupnorm_act, supported
+        mods = list(self.network)
+        x, i = input, 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, nn.GroupNorm) and isinstance(nxt, (nn.ReLU, nn.LeakyReLU)) and supported(x):
+                slope = nxt.negative_slope if isinstance(nxt, nn.LeakyReLU) else 0.0
+                x = groupnorm_act(x, m.weight, m.bias, m.num_groups, m.eps, True, slope)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 class DepthNet(EncoderDecoder):

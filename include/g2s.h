@@ -227,6 +227,24 @@ int g2s_smooth_loss_fwd(const float *p, float *loss, int N, int H, int W, g2s_st
 int g2s_smooth_loss_bwd(const float *p, const float *gloss, float *gp, int N, int H, int W,
                         g2s_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm + (leaky-)ReLU of the depth / albedo nets (csrc/groupnorm.hip), replacing the
+ * nn.GroupNorm -> nn.ReLU / nn.LeakyReLU(0.2) pairs of GAN2Shape/networks.py:88-127.
+ *   y = act((x - mean_g) * rstd_g * gamma[c] + beta[c]),  rstd_g = 1 / sqrt(var_g + eps) (biased var)
+ * x, y, gy, dx [B, C, HW] f32 (HW % 4 == 0); gamma, beta, dgamma, dbeta [C]; mean, rstd [B, G]
+ * (written by fwd, read by bwd); act 0: none, 1: leaky-ReLU(alpha) (alpha = 0: ReLU), the
+ * backward taking the activation's slope from the sign of y.  workspace: at least
+ * g2s_groupnorm_workspace_floats(B, C, HW, G) floats, scratch of one call.  No atomics.
+ * ---------------------------------------------------------------------------------------- */
+size_t g2s_groupnorm_workspace_floats(int B, int C, int HW, int G);
+int g2s_groupnorm_act_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+                          float *rstd, float *workspace, int B, int C, int HW, int G, float eps,
+                          int act, float alpha, g2s_stream_t stream);
+int g2s_groupnorm_act_bwd(const float *gy, const float *y, const float *x, const float *gamma,
+                          const float *mean, const float *rstd, float *dx, float *dgamma, float *dbeta,
+                          float *workspace, int B, int C, int HW, int G, int act, float alpha,
+                          g2s_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -332,3 +332,51 @@ def test_plain_conv_matches_torch(g2s, B, cin, cout, h, k, stride):
     (gx,) = torch.autograd.grad(y, x, g)
     (gref,) = torch.autograd.grad(ref, x, g)
     torch.testing.assert_close(gx, gref, rtol=1e-4, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------- GroupNorm + act
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,groups,slope", [
+    ((1, 32, 64, 64), 8, 0.2), ((1, 128, 16, 16), 32, 0.2), ((1, 32, 128, 128), 8, 0.0),
+    ((3, 64, 32, 32), 16, 0.0), ((2, 6, 2, 2), 3, 0.0), ((1, 256, 6, 6), 32, 0.0)])
+def test_groupnorm_act_vs_oracle(g2s, shape, groups, slope):
+    """fp32 kernel vs the float64 oracle (oracle/nets.py): forward 2e-6 of the output scale,
+    gradients 2e-5 of their scale (sums of up to 65536 fp32 terms)."""
+    from gan2shape_amd.op.groupnorm import groupnorm_act
+    from oracle import nets
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal(shape) * 2 + 0.5).astype(np.float32)
+    gamma = rng.standard_normal(shape[1]).astype(np.float32)
+    beta = rng.standard_normal(shape[1]).astype(np.float32)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    xt, gt, bt = dev(x).requires_grad_(True), dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
+    y = groupnorm_act(xt, gt, bt, groups, 1e-5, True, slope)
+    y.backward(dev(gy))
+    ref = nets.group_norm_act(x, gamma, beta, groups, 1e-5, True, slope)
+    dx, dg, db = nets.group_norm_act_grad(x, gamma, beta, gy, groups, 1e-5, True, slope)
+    # samples whose pre-activation rounds across zero flip the slope: exclude |y| < 1e-5
+    ok = np.abs(nets.group_norm_act(x, gamma, beta, groups, 1e-5, False)) > 1e-5
+    np.testing.assert_allclose(y.detach().cpu().numpy()[ok], ref[ok], rtol=0, atol=2e-6 * np.abs(ref).max())
+    for got, want in ((xt.grad, dx), (gt.grad, dg), (bt.grad, db)):
+        g = got.cpu().numpy()
+        if want.shape == x.shape:  # dx couples all elements of a group: compare where no flip is near
+            np.testing.assert_allclose(g, want, rtol=0, atol=2e-5 * np.abs(want).max() + 1e-6)
+        else:
+            np.testing.assert_allclose(g, want, rtol=0, atol=2e-5 * np.abs(want).max() + 1e-6)
+
+
+@pytest.mark.gpu
+def test_encoder_decoder_fused_groupnorm_matches_modules(g2s):
+    """DepthNet on the GPU (fused GroupNorm + activation) equals the same module list run op by op."""
+    from gan2shape_amd.networks import DepthNet
+    torch.manual_seed(0)
+    net = DepthNet(128).cuda()
+    x = torch.randn(1, 3, 128, 128, device="cuda")
+    y = net(x)
+    ref = net.network(x)
+    assert torch.allclose(y, ref, rtol=1e-4, atol=1e-5), float((y - ref).abs().max())
+    gy = torch.randn_like(y)
+    g1 = torch.autograd.grad(y, list(net.parameters()), gy)
+    g2 = torch.autograd.grad(ref, list(net.parameters()), gy)
+    for a, b in zip(g1, g2):
+        assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-7

@@ -102,3 +102,25 @@ def test_modconv_downsample_after_blur(golden):
     xb = capi.upfirdn2d(g["down.x"], k, pad=(2, 2, 2, 2))
     y = capi.modconv(xb, w, _style_mod(g, "down"), scale, True, 2)
     np.testing.assert_allclose(y, g["down.y"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,groups,slope", [((2, 8, 6, 6), 4, 0.2), ((1, 32, 16, 16), 8, 0.0), ((3, 6, 4, 4), 6, 0.0)])
+def test_group_norm_act_oracle_matches_torch_cpu(shape, groups, slope):
+    """Pins oracle/nets.py against torch's CPU GroupNorm + (leaky-)ReLU, forward and gradients."""
+    import torch
+    from oracle import nets
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(shape) * 2 + 0.5
+    gamma, beta = rng.standard_normal(shape[1]), rng.standard_normal(shape[1])
+    gy = rng.standard_normal(shape)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    gt = torch.tensor(gamma, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.leaky_relu(torch.nn.functional.group_norm(xt, groups, gt, bt, 1e-5), slope)
+    y.backward(torch.tensor(gy))
+    np.testing.assert_allclose(nets.group_norm_act(x, gamma, beta, groups, 1e-5, True, slope), y.detach().numpy(),
+                               rtol=1e-10, atol=1e-12)
+    dx, dg, db = nets.group_norm_act_grad(x, gamma, beta, gy, groups, 1e-5, True, slope)
+    np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(dg, gt.grad.numpy(), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-9, atol=1e-11)
