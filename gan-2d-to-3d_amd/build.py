@@ -26,6 +26,7 @@ SOURCES = {
     "lpips.hip": [],
     "geometry.hip": ["-ffp-contract=off"],
     "groupnorm.hip": [],
+    "conv_wgrad.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

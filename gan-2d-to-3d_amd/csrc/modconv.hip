@@ -32,7 +32,7 @@ struct ConvClass {  // one output-parity class (a single class for gather geomet
     int OH, OW;     // class output extent
     int T;          // taps in this class
     int oy0, ox0;   // offset of the class in the full output
-    int tab[9];     // per tap: (dy + 8) | (dx + 8) << 8 | wtap << 16
+    int tab[25];    // per tap: (dy + 8) | (dx + 8) << 8 | wtap << 16
 };
 
 struct ConvDesc {
@@ -57,8 +57,13 @@ struct ConvDesc {
 // A thread's elements of a tile then keep the same (channel-in-tile, tap) for the entire K loop,
 // so tap offsets, bounds checks and LDS addresses are computed ONCE; per tile only the channel base
 // moves.  This keeps the VALU work per tile (~60 instructions) far below the MFMA time.
-constexpr int BK_MAX = 18;
-template <int T> struct KTile { static constexpr int BKT = (T == 9) ? 18 : 16; static constexpr int CPT = BKT / T; };
+// 5x5 kernels (25 taps) take one channel per tile, padded to 26 rows, in a kernel instance of their
+// own (KMAX = 26) so that the common instances keep their smaller LDS footprint.
+template <int T> struct KTile {
+    static constexpr int BKT = (T == 9) ? 18 : (T == 25) ? 26 : 16;
+    static constexpr int CPT = BKT / T;
+    static constexpr int KMAX = (T == 25) ? 26 : 18;
+};
 
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 
@@ -66,9 +71,10 @@ typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 // SCALE: an input scale (style / demod) multiplies the im2col operand on its way into LDS.
 template <int BM, int BN, int T, bool PARTIAL, bool SCALE>
 __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass &c,
-                                             float (&As)[2][BK_MAX][BM + 1],
-                                             float (&Bs)[2][BK_MAX + 1][BN], const int (&stab)[9]) {
-    constexpr int BKT = KTile<T>::BKT, CPT = KTile<T>::CPT;
+                                             float (&As)[2][KTile<T>::KMAX][BM + 1],
+                                             float (&Bs)[2][KTile<T>::KMAX + 1][BN],
+                                             const int (&stab)[25]) {
+    constexpr int BKT = KTile<T>::BKT, CPT = KTile<T>::CPT, BK_MAX = KTile<T>::KMAX;
     constexpr int WMT = BM / 64, WNT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
     constexpr bool WIDE = (T == 9);              // 9 contiguous taps per (m, channel): 3 x dwordx3
     constexpr int EA = WIDE ? (BM * 6 + NTHREADS - 1) / NTHREADS : (BM * BKT + NTHREADS - 1) / NTHREADS;
@@ -112,7 +118,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
         const int dch = k / T, t = k - dch * T;
         const int tb = stab[t < T ? t : 0];
         const int iy = iy0 + (tb & 0xff) - 8, ix = ix0 + ((tb >> 8) & 0xff) - 8;
-        const bool ok = n_ok && k < BKT && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+        const bool ok = n_ok && k < BKT && dch < CPT && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
         offB[e] = ok ? (((bb * d.Cr + dch) * d.H + iy) * d.W + ix) * 4 : OOB;
         dchB[e] = dch;
     }
@@ -132,7 +138,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
         } else {
             const int k = idx % BKT, m = idx / BKT;
             const int dch = k / T, t = k - dch * T;
-            const bool ok = idx < BM * BKT && m0 + m < d.M;
+            const bool ok = idx < BM * BKT && dch < CPT && m0 + m < d.M;
             offA[e] = ok ? ((m0 + m) * d.w_ms + dch * d.w_ks + (stab[t] >> 16)) * 4 : OOB;
             ldsA[e] = (idx < BM * BKT) ? k * (BM + 1) + m : BM;  // surplus lands in the row padding
             dchA[e] = dch;
@@ -298,15 +304,15 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
 }
 
 static __host__ __device__ inline int ktiles_of(int Cr, int T) {
-    const int cpt = (T == 9) ? 2 : 16 / T;
+    const int cpt = (T == 9) ? 2 : (T == 25) ? 1 : 16 / T;
     return (Cr + cpt - 1) / cpt;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int KMAX>
 __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
-    __shared__ float As[2][BK_MAX][BM + 1];
-    __shared__ float Bs[2][BK_MAX + 1][BN];
-    __shared__ int stab[9];
+    __shared__ float As[2][KMAX][BM + 1];
+    __shared__ float Bs[2][KMAX + 1][BN];
+    __shared__ int stab[25];
     const ConvClass &c = d.cls[blockIdx.z];
     // uniform early exits: smaller parity classes need fewer tiles; empty split-K slices
     const int tiles_m = (d.M + BM - 1) / BM;
@@ -314,9 +320,13 @@ __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
     const int ktiles = ktiles_of(d.Cr, c.T);
     const int per = (ktiles + d.splitk - 1) / d.splitk;
     if ((int)blockIdx.y * per >= ktiles) return;
-    if (threadIdx.x < 9) stab[threadIdx.x] = c.tab[threadIdx.x];
+    if (threadIdx.x < 25) stab[threadIdx.x] = c.tab[threadIdx.x];
     __syncthreads();
     const bool scale = d.in_scale != nullptr;
+    if constexpr (KMAX == 26) {  // 5x5 (never modulated)
+        modconv_body<BM, BN, 25, true, false>(d, c, As, Bs, stab);
+        return;
+    } else
     switch (c.T) {  // compile-time tap count (and, for the hot 3x3 case, no partial-tile checks)
     case 9:
         if (d.Cr % 2) {
@@ -326,6 +336,9 @@ __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
             if (scale) modconv_body<BM, BN, 9, false, true>(d, c, As, Bs, stab);
             else modconv_body<BM, BN, 9, false, false>(d, c, As, Bs, stab);
         }
+        break;
+    case 16:  // 4x4 (never modulated)
+        modconv_body<BM, BN, 16, true, false>(d, c, As, Bs, stab);
         break;
     case 4:
         if (scale) modconv_body<BM, BN, 4, true, true>(d, c, As, Bs, stab);
@@ -366,15 +379,25 @@ extern "C" int g2s_modconv_tune(int tile, int splitk) {
     return G2S_OK;
 }
 
-static int modconv_launch(const float *x, const float *w, const float *in_scale,
-                          const float *out_scale, const float *bias, int act, float act_alpha,
-                          float act_gain, float *y, int B, int Cin, int Cout, int H, int W, int k,
-                          int mode, int transpose, g2s_stream_t stream) {
+// General geometry of one launch.
+//   adjoint = 0 (gather):  y[b,m,oy,ox]            = sum_{c,ky,kx} x[b,c,oy*s+ky-p,ox*s+kx-p] W(m,c,ky,kx)
+//   adjoint = 1 (scatter): y[b,m,iy*s+ky-p,ix*s+kx-p] += x[b,c,iy,ix] W(m,c,ky,kx)   (out_h x out_w given)
+//   W(m,c,ky,kx) = w[m*w_ms + c*w_ks + ky*k + kx]:  m_major: w is [M, Cr, k, k], else [Cr, M, k, k].
+struct ConvGeom {
+    int k, stride, pad, adjoint, m_major;
+    int out_h, out_w;  // adjoint only; 0 = (H-1)*s - 2p + k
+};
+
+static int conv_launch(const float *x, const float *w, const float *in_scale, const float *out_scale,
+                       const float *bias, int act, float act_alpha, float act_gain, float *y, int B,
+                       int Cr, int M, int H, int W, const ConvGeom &g, int tuned_tile, int tuned_splitk,
+                       g2s_stream_t stream) {
     G2S_REQUIRE(x && w && y, "x, w, y must not be NULL");
-    G2S_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "sizes must be positive");
-    G2S_REQUIRE(k == 1 || k == 3, "kernel size must be 1 or 3 (got %d)", k);
-    G2S_REQUIRE(mode == G2S_CONV_PLAIN || mode == G2S_CONV_UP2 || mode == G2S_CONV_DOWN2,
-                "unsupported mode %d", mode);
+    G2S_REQUIRE(B > 0 && Cr > 0 && M > 0 && H > 0 && W > 0, "sizes must be positive");
+    const int k = g.k, s_ = g.stride, p_ = g.pad, KK = k * k;
+    G2S_REQUIRE(k >= 1 && k <= 5, "kernel size must be 1..5 (got %d)", k);
+    G2S_REQUIRE(s_ == 1 || s_ == 2, "stride must be 1 or 2 (got %d)", s_);
+    G2S_REQUIRE(p_ >= 0 && p_ < k, "padding must be in [0, k)");
     ConvDesc d{};
     d.x = x;
     d.w = w;
@@ -388,58 +411,64 @@ static int modconv_launch(const float *x, const float *w, const float *in_scale,
     d.B = B;
     d.H = H;
     d.W = W;
-    const int KK = k * k, pad = k / 2;
-    d.Cr = transpose ? Cout : Cin;
-    d.M = transpose ? Cin : Cout;
-    d.w_ms = transpose ? KK : Cin * KK;
-    d.w_ks = transpose ? Cin * KK : KK;
-    d.w_bytes = Cout * Cin * KK * 4;
-    // geometry: gather (stride 1 or 2) or polyphase scatter
-    const bool scatter = (mode == G2S_CONV_UP2 && !transpose) || (mode == G2S_CONV_DOWN2 && transpose);
-    if (!scatter) {
+    d.Cr = Cr;
+    d.M = M;
+    d.w_ms = g.m_major ? Cr * KK : KK;
+    d.w_ks = g.m_major ? KK : M * KK;
+    d.w_bytes = M * Cr * KK * 4;
+    bool holes = false;  // output positions no class writes (zero-filled)
+    if (!g.adjoint) {
+        G2S_REQUIRE(H + 2 * p_ >= k && W + 2 * p_ >= k, "input smaller than the kernel");
         d.ncls = 1;
         d.os = 1;
+        d.is = s_;
+        d.OHf = (H + 2 * p_ - k) / s_ + 1;
+        d.OWf = (W + 2 * p_ - k) / s_ + 1;
         ConvClass &c = d.cls[0];
         c.T = KK;
         c.oy0 = c.ox0 = 0;
-        if (mode == G2S_CONV_PLAIN) {
-            d.is = 1;
-            d.OHf = H;
-            d.OWf = W;
-            for (int ky = 0; ky < k; ky++)
-                for (int kx = 0; kx < k; kx++)
-                    c.tab[ky * k + kx] = transpose ? pack(pad - ky, pad - kx, ky * k + kx)
-                                                   : pack(ky - pad, kx - pad, ky * k + kx);
-        } else {  // strided gather: DOWN2 forward, or the adjoint of UP2
-            G2S_REQUIRE(H >= k && W >= k, "input smaller than the kernel");
-            d.is = 2;
-            d.OHf = (H - k) / 2 + 1;
-            d.OWf = (W - k) / 2 + 1;
-            for (int ky = 0; ky < k; ky++)
-                for (int kx = 0; kx < k; kx++) c.tab[ky * k + kx] = pack(ky, kx, ky * k + kx);
-        }
         c.OH = d.OHf;
         c.OW = d.OWf;
+        for (int ky = 0; ky < k; ky++)
+            for (int kx = 0; kx < k; kx++) c.tab[ky * k + kx] = pack(ky - p_, kx - p_, ky * k + kx);
     } else {
-        // y[2*iy + ky] += x[iy] w[ky]: output parity p uses taps ky == p (mod 2), iy = oy' + (p - ky)/2
+        d.OHf = g.out_h ? g.out_h : (H - 1) * s_ - 2 * p_ + k;
+        d.OWf = g.out_w ? g.out_w : (W - 1) * s_ - 2 * p_ + k;
+        G2S_REQUIRE(d.OHf >= (H - 1) * s_ - 2 * p_ + k && d.OWf >= (W - 1) * s_ - 2 * p_ + k &&
+                        d.OHf <= (H - 1) * s_ - 2 * p_ + k + s_ - 1 && d.OWf <= (W - 1) * s_ - 2 * p_ + k + s_ - 1,
+                    "adjoint output size %dx%d inconsistent with the input", d.OHf, d.OWf);
         d.is = 1;
-        d.os = 2;
-        d.OHf = (H - 1) * 2 + k;
-        d.OWf = (W - 1) * 2 + k;
-        d.ncls = 4;
-        for (int py = 0; py < 2; py++)
-            for (int px = 0; px < 2; px++) {
-                ConvClass &c = d.cls[py * 2 + px];
-                c.oy0 = py;
-                c.ox0 = px;
-                c.OH = (d.OHf - py + 1) / 2;
-                c.OW = (d.OWf - px + 1) / 2;
+        d.os = s_;
+        d.ncls = 0;
+        // output row oy = iy*s + ky - p: residue class r = oy mod s uses the taps ky == r + p (mod s),
+        // read at iy = oy' + (r + p - ky) / s  (oy = oy'*s + r).  No multiplications by inserted zeros.
+        for (int ry = 0; ry < s_; ry++)
+            for (int rx = 0; rx < s_; rx++) {
+                ConvClass c{};
+                c.oy0 = ry;
+                c.ox0 = rx;
+                c.OH = (d.OHf - ry + s_ - 1) / s_;
+                c.OW = (d.OWf - rx + s_ - 1) / s_;
                 c.T = 0;
-                for (int ky = py; ky < k; ky += 2)
-                    for (int kx = px; kx < k; kx += 2)
-                        c.tab[c.T++] = pack((py - ky) / 2, (px - kx) / 2, ky * k + kx);
+                for (int ky = 0; ky < k; ky++)
+                    for (int kx = 0; kx < k; kx++)
+                        if ((ry + p_ - ky) % s_ == 0 && (rx + p_ - kx) % s_ == 0)
+                            c.tab[c.T++] = pack((ry + p_ - ky) / s_, (rx + p_ - kx) / s_, ky * k + kx);
+                if (c.T == 0 || c.OH <= 0 || c.OW <= 0) {
+                    holes = holes || (c.OH > 0 && c.OW > 0);
+                    continue;
+                }
+                d.cls[d.ncls++] = c;
             }
-        if (k == 1) d.ncls = 1;  // only parity (0,0) receives data; the rest of y is zero-filled below
+        G2S_REQUIRE(d.ncls > 0, "empty convolution");
+    }
+    bool big = false;
+    for (int i = 0; i < d.ncls; i++) {
+        const int T = d.cls[i].T;
+        G2S_REQUIRE(T == 1 || T == 2 || T == 4 || T == 9 || T == 16 || T == 25,
+                    "unsupported tap count %d (k=%d stride=%d)", T, k, s_);
+        G2S_REQUIRE(!(in_scale && T > 9), "input scales are limited to kernels of up to 3x3");
+        big = big || T == 25;
     }
     // tile configuration + split-K: aim for >= 2 workgroups (8 waves) per CU
     long nmax = 0;
@@ -448,7 +477,7 @@ static int modconv_launch(const float *x, const float *w, const float *in_scale,
         nmax = std::max(nmax, (long)B * d.cls[i].OH * d.cls[i].OW);
         kt_min = std::min(kt_min, ktiles_of(d.Cr, d.cls[i].T));
     }
-    G2S_REQUIRE(nmax < (1l << 30) && (long)B * d.Cr * H * W < (1l << 29) && (long)Cout * Cin * KK < (1l << 29),
+    G2S_REQUIRE(nmax < (1l << 30) && (long)B * d.Cr * H * W < (1l << 29) && (long)M * Cr * KK < (1l << 29),
                 "problem too large for 32-bit byte offsets");
     hipStream_t st = as_stream(stream);
     const int cfgs[3][2] = {{128, 128}, {128, 64}, {64, 64}};
@@ -457,15 +486,8 @@ static int modconv_launch(const float *x, const float *w, const float *in_scale,
         const long blocks = (long)cdiv(d.M, cfgs[i][0]) * cdiv(nmax, cfgs[i][1]) * d.ncls;
         if (d.M > cfgs[i][0] / 2 && blocks >= 512) { pick = i; break; }
     }
-    int tuned_splitk = -1;
-    if (H == W && g_force_tile != -2)
-        for (const TunedConv *t = kTuned; t->B; ++t)
-            if (t->B == B && t->Cin == Cin && t->Cout == Cout && t->H == H && t->k == k && t->mode == mode &&
-                t->transpose == transpose && t->fused == (bias != nullptr || act != 0)) {
-                pick = t->tile;
-                tuned_splitk = t->splitk;
-                break;
-            }
+    if (tuned_tile >= 0 && g_force_tile != -2) pick = tuned_tile;
+    else tuned_splitk = -1;
     if (g_force_tile >= 0) pick = g_force_tile;
     const int BMv = cfgs[pick][0], BNv = cfgs[pick][1];
     const int tiles = cdiv(d.M, BMv) * cdiv(nmax, BNv);
@@ -482,19 +504,56 @@ static int modconv_launch(const float *x, const float *w, const float *in_scale,
         d.act = 0;
     }
     d.splitk = splitk;
-    if (splitk > 1 || (scatter && k == 1)) {
+    if (splitk > 1 || holes) {
         if (hipMemsetAsync(y, 0, (size_t)B * d.M * d.OHf * d.OWf * sizeof(float), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
     }
     dim3 grid(tiles, splitk, d.ncls);
-    if (pick == 0) modconv_kernel<128, 128><<<grid, NTHREADS, 0, st>>>(d);
-    else if (pick == 1) modconv_kernel<128, 64><<<grid, NTHREADS, 0, st>>>(d);
-    else modconv_kernel<64, 64><<<grid, NTHREADS, 0, st>>>(d);
+    if (big) {
+        if (pick == 0) modconv_kernel<128, 128, 26><<<grid, NTHREADS, 0, st>>>(d);
+        else if (pick == 1) modconv_kernel<128, 64, 26><<<grid, NTHREADS, 0, st>>>(d);
+        else modconv_kernel<64, 64, 26><<<grid, NTHREADS, 0, st>>>(d);
+    } else {
+        if (pick == 0) modconv_kernel<128, 128, 18><<<grid, NTHREADS, 0, st>>>(d);
+        else if (pick == 1) modconv_kernel<128, 64, 18><<<grid, NTHREADS, 0, st>>>(d);
+        else modconv_kernel<64, 64, 18><<<grid, NTHREADS, 0, st>>>(d);
+    }
     int rc = check_launch("g2s_modconv");
     if (rc != G2S_OK || !deferred_epilogue) return rc;
     return g2s_fused_bias_act(y, bias, nullptr, y, (int64_t)B * d.M * d.OHf * d.OWf,
                               (int64_t)d.OHf * d.OWf, d.M, act ? 3 : 1, 0, act_alpha,
                               act ? act_gain : 1.0f, G2S_F32, stream);
+}
+
+// The StyleGAN2 modes of g2s_modconv in terms of the general geometry (w is always [Cout, Cin, k, k]).
+static int modconv_launch(const float *x, const float *w, const float *in_scale,
+                          const float *out_scale, const float *bias, int act, float act_alpha,
+                          float act_gain, float *y, int B, int Cin, int Cout, int H, int W, int k,
+                          int mode, int transpose, g2s_stream_t stream) {
+    G2S_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "sizes must be positive");
+    G2S_REQUIRE(k == 1 || k == 3, "kernel size must be 1 or 3 (got %d)", k);
+    G2S_REQUIRE(mode == G2S_CONV_PLAIN || mode == G2S_CONV_UP2 || mode == G2S_CONV_DOWN2,
+                "unsupported mode %d", mode);
+    ConvGeom g{};
+    g.k = k;
+    g.stride = mode == G2S_CONV_PLAIN ? 1 : 2;
+    g.pad = mode == G2S_CONV_PLAIN ? k / 2 : 0;
+    // UP2 is the scatter; a transposed call runs the adjoint geometry with the roles of Cin / Cout
+    // (and therefore the two weight strides) swapped
+    g.adjoint = (mode == G2S_CONV_UP2) != (transpose != 0);
+    g.m_major = !transpose;
+    if (!g.adjoint && mode != G2S_CONV_PLAIN) G2S_REQUIRE(H >= k && W >= k, "input smaller than the kernel");
+    int tile = -1, splitk = -1;
+    if (H == W)
+        for (const TunedConv *t = kTuned; t->B; ++t)
+            if (t->B == B && t->Cin == Cin && t->Cout == Cout && t->H == H && t->k == k && t->mode == mode &&
+                t->transpose == transpose && t->fused == (bias != nullptr || act != 0)) {
+                tile = t->tile;
+                splitk = t->splitk;
+                break;
+            }
+    return conv_launch(x, w, in_scale, out_scale, bias, act, act_alpha, act_gain, y, B,
+                       transpose ? Cout : Cin, transpose ? Cin : Cout, H, W, g, tile, splitk, stream);
 }
 
 extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale,
@@ -510,4 +569,12 @@ extern "C" int g2s_conv_bias_act(const float *x, const float *w, const float *bi
     G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
     return modconv_launch(x, w, nullptr, nullptr, bias, act, alpha, gain, y, B, Cin, Cout, H, W, k,
                           mode, 0, stream);
+}
+
+extern "C" int g2s_conv2d(const float *x, const float *w, const float *bias, float *y, int B, int Cr,
+                          int M, int H, int W, int k, int stride, int pad, int adjoint, int w_m_major,
+                          int out_h, int out_w, int act, float alpha, float gain, g2s_stream_t stream) {
+    G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
+    ConvGeom g{k, stride, pad, adjoint ? 1 : 0, w_m_major ? 1 : 0, adjoint ? out_h : 0, adjoint ? out_w : 0};
+    return conv_launch(x, w, nullptr, nullptr, bias, act, alpha, gain, y, B, Cr, M, H, W, g, -1, -1, stream);
 }

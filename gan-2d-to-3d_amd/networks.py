@@ -1,13 +1,45 @@
 """D / A / V / L / E networks of GAN2Shape (arxiv 2011.00844, tables 5-8), state-dict compatible
-with GAN2Shape/networks.py:23-244 (`network.<idx>.weight` keys).  Convolutions run as plain torch.nn
-on MIOpen (these nets are callers inside the step); the GroupNorm + activation pairs of the depth /
-albedo nets run as one fused op on the GPU.
+with GAN2Shape/networks.py:23-244 (`network.<idx>.weight` keys).  On the GPU the convolutions
+(forward, data- and weight-gradient) and the GroupNorm + activation pairs run on libg2s.so
+(run_fused); on the CPU the same module lists run as plain torch.nn.
 
 PSPNet / BiSeNet / ResNet (networks.py:247-586) only feed the one-shot masking model and are out
 of scope.  The debug gradient alerts (debug_grad_updates.py) are dropped; `debug` is accepted and
 ignored.
 """
 import torch.nn as nn
+
+
+def run_fused(mods, x):
+    """Run a list of modules on the GPU with the pairs libg2s.so fuses: Conv2d / ConvTranspose2d
+    (+ ReLU / LeakyReLU) on the fp32-MFMA convolution (op/conv.py), GroupNorm + ReLU / LeakyReLU
+    as one op (op/groupnorm.py).  Module list and parameters — and so the state dict — are those of
+    the reference nets; results equal the op-by-op evaluation up to fp32 summation order."""
+    from .op import conv as gconv
+    from .op.groupnorm import groupnorm_act, supported as gn_supported
+    mods = list(mods)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        slope = None
+        if isinstance(nxt, nn.LeakyReLU):
+            slope = nxt.negative_slope
+        elif isinstance(nxt, nn.ReLU):
+            slope = 0.0
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and gconv.supported(m, x):
+            x = gconv.conv_module(m, x, slope)
+            i += 2 if slope is not None else 1
+        elif isinstance(m, nn.GroupNorm) and slope is not None and gn_supported(x):
+            x = groupnorm_act(x, m.weight, m.bias, m.num_groups, m.eps, True, slope)
+            i += 2
+        elif isinstance(m, nn.Sequential):
+            x = run_fused(m, x)
+            i += 1
+        else:
+            x = m(x)
+            i += 1
+    return x
 
 
 class Encoder(nn.Module):
@@ -28,7 +60,8 @@ class Encoder(nn.Module):
         self.network = nn.Sequential(*layers)
 
     def forward(self, input):
-        return self.network(input).reshape(input.size(0), -1)
+        out = run_fused(self.network, input) if input.is_cuda else self.network(input)
+        return out.reshape(input.size(0), -1)
 
 
 class ViewpointNet(Encoder):
@@ -81,24 +114,7 @@ class EncoderDecoder(nn.Module):
         self.network = nn.Sequential(*network)
 
     def forward(self, input):
-        if not input.is_cuda:
-            return self.network(input)
-        # GPU: every GroupNorm + ReLU / LeakyReLU pair is one op of libg2s.so (2 launches forward,
-        # 2 backward, instead of 4 + 5); the module list — and so the state dict — is unchanged
-        from .op.groupnorm import groupnorm_act, supported
-        mods = list(self.network)
-        x, i = input, 0
-        while i < len(mods):
-            m = mods[i]
-            nxt = mods[i + 1] if i + 1 < len(mods) else None
-            if isinstance(m, nn.GroupNorm) and isinstance(nxt, (nn.ReLU, nn.LeakyReLU)) and supported(x):
-                slope = nxt.negative_slope if isinstance(nxt, nn.LeakyReLU) else 0.0
-                x = groupnorm_act(x, m.weight, m.bias, m.num_groups, m.eps, True, slope)
-                i += 2
-            else:
-                x = m(x)
-                i += 1
-        return x
+        return run_fused(self.network, input) if input.is_cuda else self.network(input)
 
 
 class DepthNet(EncoderDecoder):
@@ -124,6 +140,8 @@ class ResBlock(nn.Module):
             nn.Conv2d(cin, cout, kernel_size=1, stride=1, padding=0))
 
     def forward(self, x):
+        if x.is_cuda:
+            return run_fused(self.identity_path, x) + run_fused(self.res_path, x)
         return self.identity_path(x) + self.res_path(x)
 
 
@@ -150,4 +168,5 @@ class OffsetEncoder(nn.Module):
         self.network = nn.Sequential(*network)
 
     def forward(self, x):
-        return self.network(x).reshape(x.size(0), -1)
+        out = run_fused(self.network, x) if x.is_cuda else self.network(x)
+        return out.reshape(x.size(0), -1)

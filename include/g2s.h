@@ -150,6 +150,26 @@ int g2s_conv_bias_act(const float *x, const float *w, const float *bias, float *
                       int Cout, int H, int W, int k, int mode, int act, float alpha, float gain,
                       g2s_stream_t stream);
 
+/* General 2-D convolution on the same fp32-MFMA implicit-GEMM kernel: the trained nets of the step
+ * (depth / albedo / viewpoint / lighting / offset-encoder nets, GAN2Shape/networks.py:23-244:
+ * nn.Conv2d k in {1,3,4,5} stride 1/2, nn.ConvTranspose2d k4 stride 1/2), forward and data-gradient.
+ *   adjoint = 0: y[b,m,oy,ox]               = sum_{c,ky,kx} x[b,c,oy*s+ky-p,ox*s+kx-p] W(m,c,ky,kx),
+ *                out ((H+2p-k)/s+1) x ((W+2p-k)/s+1)                    (Conv2d forward; ConvTranspose2d dgrad)
+ *   adjoint = 1: y[b,m,iy*s+ky-p,ix*s+kx-p] += x[b,c,iy,ix] W(m,c,ky,kx), out out_h x out_w, 0 = (H-1)s-2p+k
+ *                (up to s-1 more, as a strided Conv2d's input can be)    (ConvTranspose2d forward; Conv2d dgrad)
+ *   W(m,c,ky,kx) = w[(m*Cr + c)*k*k + ky*k + kx] if w_m_major (w is [M,Cr,k,k]) else w[(c*M + m)*k*k + ...]
+ * x [B,Cr,H,W], y [B,M,...] f32, fully overwritten; bias [M] or NULL, act as g2s_conv_bias_act.
+ * k 1..5, stride 1 or 2, 0 <= pad < k.
+ * g2s_conv2d_wgrad: dw[a,g,ky,kx] = sum_{b,py,px} A[b,a,py,px] * G[b,g,py*s+ky-p,px*s+kx-p]
+ *   (zero outside G), A [B,Ca,PH,PW], G [B,Cg,GH,GW], dw [Ca,Cg,k,k] fully overwritten.
+ *   Conv2d weight gradient: A = grad_out, G = input; ConvTranspose2d: A = input, G = grad_out.
+ *   Summation over pixels is split over workgroups and added with float atomics. */
+int g2s_conv2d(const float *x, const float *w, const float *bias, float *y, int B, int Cr, int M, int H,
+               int W, int k, int stride, int pad, int adjoint, int w_m_major, int out_h, int out_w,
+               int act, float alpha, float gain, g2s_stream_t stream);
+int g2s_conv2d_wgrad(const float *A, const float *G, float *dw, int B, int Ca, int Cg, int PH, int PW,
+                     int GH, int GW, int k, int stride, int pad, g2s_stream_t stream);
+
 /* Tuning hook (tools/tune_modconv.py): force the tile configuration (0: 128x128, 1: 128x64,
  * 2: 64x64 output channels x pixels) and/or the split-K factor of the calling thread's following
  * g2s_modconv / g2s_conv_bias_act launches; -1 restores the built-in choice (measured table

@@ -365,18 +365,65 @@ def test_groupnorm_act_vs_oracle(g2s, shape, groups, slope):
             np.testing.assert_allclose(g, want, rtol=0, atol=2e-5 * np.abs(want).max() + 1e-6)
 
 
+# ----------------------------------------------------------------------------- general conv (trained nets)
+CONV_CASES = [  # B, Cin, Cout, H, k, stride, pad, transposed, slope
+    (1, 3, 32, 128, 4, 2, 1, False, 0.2), (1, 32, 64, 64, 4, 2, 1, False, None), (1, 128, 256, 16, 4, 2, 1, False, 0.2),
+    (1, 256, 256, 4, 4, 1, 0, False, 0.0), (1, 256, 256, 1, 4, 1, 0, True, 0.0), (1, 256, 128, 8, 4, 2, 1, True, None),
+    (1, 64, 32, 32, 4, 2, 1, True, None), (1, 32, 32, 128, 5, 1, 2, False, None), (1, 32, 3, 128, 5, 1, 2, False, None),
+    (1, 32, 32, 64, 3, 1, 1, False, None), (9, 3, 32, 128, 4, 2, 1, False, 0.0), (9, 512, 512, 4, 4, 1, 0, False, 0.0),
+    (9, 512, 6, 1, 1, 1, 0, False, None), (9, 32, 64, 64, 3, 2, 1, False, None), (9, 32, 64, 32, 1, 1, 0, False, None),
+    (2, 5, 7, 11, 3, 2, 1, False, None), (2, 5, 7, 9, 4, 2, 1, True, 0.0), (2, 6, 4, 7, 5, 1, 2, False, 0.1),
+    (2, 3, 5, 10, 4, 2, 1, False, None), (3, 4, 6, 6, 5, 1, 0, True, None), (2, 7, 3, 12, 3, 2, 0, False, None),
+]
+
+
 @pytest.mark.gpu
-def test_encoder_decoder_fused_groupnorm_matches_modules(g2s):
-    """DepthNet on the GPU (fused GroupNorm + activation) equals the same module list run op by op."""
-    from gan2shape_amd.networks import DepthNet
+@pytest.mark.parametrize("B,cin,cout,H,k,stride,pad,transposed,slope", CONV_CASES)
+def test_conv_function_matches_torch_f64(g2s, B, cin, cout, H, k, stride, pad, transposed, slope):
+    """g2s_conv2d (forward, data-gradient) and g2s_conv2d_wgrad against torch's float64 CPU
+    convolution: 2e-5 of each tensor's L2 norm (fp32 MFMA sums of up to ~10^5 terms)."""
+    import torch.nn.functional as F
+    from gan2shape_amd.op.conv import ConvFunction
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, cin, H, H + (1 if H % 2 and H > 4 else 0), generator=gen, dtype=torch.float64)
+    wshape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+    w = torch.randn(wshape, generator=gen, dtype=torch.float64) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=gen, dtype=torch.float64)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = (F.conv_transpose2d if transposed else F.conv2d)(xr, wr, br, stride=stride, padding=pad)
+    if slope is not None:
+        ref = F.leaky_relu(ref, slope)
+    gy = torch.randn(ref.shape, generator=gen, dtype=torch.float64)
+    ref.backward(gy)
+    xg, wg, bg = [t.float().cuda().requires_grad_(True) for t in (x, w, b)]
+    y = ConvFunction.apply(xg, wg, bg, stride, pad, transposed, slope)
+    assert y.shape == ref.shape
+    y.backward(gy.float().cuda())
+
+    def close(got, want, what):
+        err = float((got.double().cpu() - want).norm())
+        assert err <= 2e-5 * float(want.norm()) + 1e-7, (what, err, float(want.norm()))
+    close(y.detach(), ref.detach(), "y")
+    close(xg.grad, xr.grad, "gx")
+    close(wg.grad, wr.grad, "gw")
+    close(bg.grad, br.grad, "gb")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["DepthNet", "AlbedoNet", "ViewpointNet", "LightingNet", "OffsetEncoder"])
+def test_trained_nets_fused_match_modules(g2s, name):
+    """Each trained net on the GPU (libg2s convolutions + fused GroupNorm) equals its own module
+    list evaluated op by op by torch (MIOpen), outputs and parameter gradients."""
+    from gan2shape_amd import networks
     torch.manual_seed(0)
-    net = DepthNet(128).cuda()
-    x = torch.randn(1, 3, 128, 128, device="cuda")
+    net = getattr(networks, name)(128).cuda()
+    B = 1 if name in ("DepthNet", "AlbedoNet") else 3
+    x = torch.randn(B, 3, 128, 128, device="cuda")
     y = net(x)
-    ref = net.network(x)
-    assert torch.allclose(y, ref, rtol=1e-4, atol=1e-5), float((y - ref).abs().max())
+    ref = net.network(x).reshape(y.shape)
+    assert float((y - ref).norm()) <= 1e-4 * float(ref.norm()) + 1e-6
     gy = torch.randn_like(y)
     g1 = torch.autograd.grad(y, list(net.parameters()), gy)
     g2 = torch.autograd.grad(ref, list(net.parameters()), gy)
     for a, b in zip(g1, g2):
-        assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-7
+        assert float((a - b).norm()) <= 2e-4 * float(b.norm()) + 1e-6

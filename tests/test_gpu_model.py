@@ -393,7 +393,7 @@ def test_step3_batched_nets_equal_reference_order(trainer):
     for n, p in m.named_parameters():
         if p.grad is not None:
             ref = p.grad
-            assert float((gb[n] - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-9, n
+            assert float((gb[n] - ref).norm()) <= 5e-3 * float(ref.norm()) + 1e-9, n  # split-K atomics reorder sums
 
 
 def test_trainer_fit_with_hip_graphs():
