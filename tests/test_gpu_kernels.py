@@ -251,7 +251,9 @@ def test_modulated_conv_golden(g2s, golden, name):
 
 @pytest.mark.parametrize("B,cin,cout,h,k,mode", [
     (2, 64, 96, 16, 3, 0), (3, 40, 130, 9, 3, 0), (2, 64, 64, 8, 3, 1), (2, 32, 48, 13, 3, 2),
-    (2, 128, 3, 32, 1, 0), (8, 512, 512, 4, 3, 0), (2, 256, 128, 16, 3, 1), (1, 8, 8, 5, 3, 1)])
+    (2, 128, 3, 32, 1, 0), (8, 512, 512, 4, 3, 0), (2, 256, 128, 16, 3, 1), (1, 8, 8, 5, 3, 1),
+    # <= 4 channels on one side
+    (2, 3, 40, 32, 1, 0), (2, 3, 24, 33, 3, 0), (2, 21, 3, 32, 3, 0), (2, 66, 2, 40, 3, 0), (1, 4, 130, 32, 3, 0)])
 def test_modconv_vs_oracle(g2s, B, cin, cout, h, k, mode):
     from gan2shape_amd.modconv import modconv_raw
     rng = np.random.default_rng(2)
@@ -278,6 +280,20 @@ def test_modconv_transpose_is_adjoint(g2s, mode, h):
     g = torch.randn_like(y)
     xt = modconv_raw(g, w, None, None, mode, 1)
     assert xt.shape == x.shape
+    lhs, rhs = (y.double() * g.double()).sum().item(), (x.double() * xt.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("cin,cout,k", [(3, 40, 3), (40, 3, 3), (3, 24, 1), (130, 2, 1)])
+def test_thin_conv_transpose_is_adjoint(g2s, cin, cout, k):
+    """Same identity with <= 4 channels on one side (toRGB / fromRGB / first VGG layer shapes)."""
+    from gan2shape_amd.modconv import modconv_raw
+    torch.manual_seed(1)
+    x = torch.randn(2, cin, 34, 34, device="cuda")
+    w = torch.randn(cout, cin, k, k, device="cuda") / 10
+    y = modconv_raw(x, w, None, None, 0, 0)
+    g = torch.randn_like(y)
+    xt = modconv_raw(g, w, None, None, 0, 1)
     lhs, rhs = (y.double() * g.double()).sum().item(), (x.double() * xt.double()).sum().item()
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
 
