@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
         modconv_body<BM, BN, 25, true, false>(d, c, As, Bs, stab);
         return;
     } else
-    switch (c.T) {  // compile-time tap count (and, for the hot 3x3 case, no partial-tile checks)
+    switch (c.T) {  // compile-time tap count; no partial-tile checks when the channels fill the K tiles
     case 9:
         if (d.Cr % 2) {
             if (scale) modconv_body<BM, BN, 9, true, true>(d, c, As, Bs, stab);
@@ -341,16 +341,31 @@ __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
         modconv_body<BM, BN, 16, true, false>(d, c, As, Bs, stab);
         break;
     case 4:
-        if (scale) modconv_body<BM, BN, 4, true, true>(d, c, As, Bs, stab);
-        else modconv_body<BM, BN, 4, true, false>(d, c, As, Bs, stab);
+        if (d.Cr % 4) {
+            if (scale) modconv_body<BM, BN, 4, true, true>(d, c, As, Bs, stab);
+            else modconv_body<BM, BN, 4, true, false>(d, c, As, Bs, stab);
+        } else {
+            if (scale) modconv_body<BM, BN, 4, false, true>(d, c, As, Bs, stab);
+            else modconv_body<BM, BN, 4, false, false>(d, c, As, Bs, stab);
+        }
         break;
     case 2:
-        if (scale) modconv_body<BM, BN, 2, true, true>(d, c, As, Bs, stab);
-        else modconv_body<BM, BN, 2, true, false>(d, c, As, Bs, stab);
+        if (d.Cr % 8) {
+            if (scale) modconv_body<BM, BN, 2, true, true>(d, c, As, Bs, stab);
+            else modconv_body<BM, BN, 2, true, false>(d, c, As, Bs, stab);
+        } else {
+            if (scale) modconv_body<BM, BN, 2, false, true>(d, c, As, Bs, stab);
+            else modconv_body<BM, BN, 2, false, false>(d, c, As, Bs, stab);
+        }
         break;
     default:
-        if (scale) modconv_body<BM, BN, 1, true, true>(d, c, As, Bs, stab);
-        else modconv_body<BM, BN, 1, true, false>(d, c, As, Bs, stab);
+        if (d.Cr % 16) {
+            if (scale) modconv_body<BM, BN, 1, true, true>(d, c, As, Bs, stab);
+            else modconv_body<BM, BN, 1, true, false>(d, c, As, Bs, stab);
+        } else {
+            if (scale) modconv_body<BM, BN, 1, false, true>(d, c, As, Bs, stab);
+            else modconv_body<BM, BN, 1, false, false>(d, c, As, Bs, stab);
+        }
         break;
     }
 }

@@ -429,17 +429,24 @@ def test_conv_function_matches_torch_f64(g2s, B, cin, cout, H, k, stride, pad, t
 @pytest.mark.parametrize("name", ["DepthNet", "AlbedoNet", "ViewpointNet", "LightingNet", "OffsetEncoder"])
 def test_trained_nets_fused_match_modules(g2s, name):
     """Each trained net on the GPU (libg2s convolutions + fused GroupNorm) equals its own module
-    list evaluated op by op by torch (MIOpen), outputs and parameter gradients."""
+    list evaluated op by op by torch on the CPU in float64: outputs to 1e-4 of their norm;
+    parameter gradients to 5e-3 — an activation whose input lies within fp32 rounding of zero takes
+    the other slope than in float64, which perturbs every gradient upstream of it (the single ops
+    are held to 2e-5 by the tests above)."""
+    import copy
     from gan2shape_amd import networks
     torch.manual_seed(0)
-    net = getattr(networks, name)(128).cuda()
+    net = getattr(networks, name)(128)
+    ref_net = copy.deepcopy(net).double()
+    net = net.cuda()
     B = 1 if name in ("DepthNet", "AlbedoNet") else 3
-    x = torch.randn(B, 3, 128, 128, device="cuda")
-    y = net(x)
-    ref = net.network(x).reshape(y.shape)
-    assert float((y - ref).norm()) <= 1e-4 * float(ref.norm()) + 1e-6
-    gy = torch.randn_like(y)
-    g1 = torch.autograd.grad(y, list(net.parameters()), gy)
-    g2 = torch.autograd.grad(ref, list(net.parameters()), gy)
-    for a, b in zip(g1, g2):
-        assert float((a - b).norm()) <= 2e-4 * float(b.norm()) + 1e-6
+    x = torch.randn(B, 3, 128, 128)
+    gen_gy = torch.Generator().manual_seed(1)
+    y = net(x.cuda())
+    ref = ref_net(x.double())
+    assert float((y.detach().double().cpu() - ref.detach()).norm()) <= 1e-4 * float(ref.norm()) + 1e-6
+    gy = torch.randn(ref.shape, generator=gen_gy, dtype=torch.float64)
+    g1 = torch.autograd.grad(y, list(net.parameters()), gy.float().cuda())
+    g2 = torch.autograd.grad(ref, list(ref_net.parameters()), gy)
+    for (n, _), a, b in zip(net.named_parameters(), g1, g2):
+        assert float((a.double().cpu() - b).norm()) <= 5e-3 * float(b.norm()) + 1e-7, n
