@@ -19,9 +19,30 @@ from . import lib as _lib
 
 PLAIN, UP2, DOWN2 = _lib.CONV_PLAIN, _lib.CONV_UP2, _lib.CONV_DOWN2
 
-# bench.py sets this to a list to collect (algorithmic FLOP, start event, end event) per launch,
-# recorded on the launch stream; None = no instrumentation.
+# bench.py sets this to a list to collect (algorithmic FLOP, start event, end event, algorithmic
+# bytes) per launch of the MFMA convolution kernel, recorded on the launch stream; None = no
+# instrumentation.
 PROFILE = None
+
+
+class profiled:
+    """with profiled(flop, nbytes): <one launch of g2s::modconv_kernel>"""
+
+    def __init__(self, flop, nbytes):
+        self.rec = PROFILE
+        self.flop, self.nbytes = flop, nbytes
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            self.e1.record()
+            self.rec.append((self.flop, self.e0, self.e1, self.nbytes))
+        return False
 
 
 def out_size(h, k, mode):
@@ -58,18 +79,12 @@ def modconv_raw(x, w, in_scale, out_scale, mode, transpose):
     si = None if in_scale is None else in_scale.contiguous()
     so = None if out_scale is None else out_scale.contiguous()
     L = _lib.load()
-    prof = PROFILE
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(L.g2s_modconv(_lib.ptr(x), _lib.ptr(w), _lib.ptr(si), _lib.ptr(so), _lib.ptr(y), B,
-                             Cin, Cout, H, W, k, mode, int(transpose), _lib.stream()))
-    if prof is not None:
-        e1.record()
-        # algorithmic FLOP: 2 * B * Cout * Cin * k^2 * (spatial positions of the un-strided side)
-        sp = min(H * W, oh * ow) if mode != PLAIN else oh * ow
-        nbytes = 4.0 * (x.numel() + w.numel() + y.numel())  # algorithmic: each operand once
-        prof.append((2.0 * B * Cout * Cin * k * k * sp, e0, e1, nbytes))
+    # algorithmic FLOP: 2 * B * Cout * Cin * k^2 * (spatial positions of the un-strided side);
+    # algorithmic bytes: each operand once
+    sp = min(H * W, oh * ow) if mode != PLAIN else oh * ow
+    with profiled(2.0 * B * Cout * Cin * k * k * sp, 4.0 * (x.numel() + w.numel() + y.numel())):
+        _lib.check(L.g2s_modconv(_lib.ptr(x), _lib.ptr(w), _lib.ptr(si), _lib.ptr(so), _lib.ptr(y), B,
+                                 Cin, Cout, H, W, k, mode, int(transpose), _lib.stream()))
     return y
 
 
@@ -232,8 +247,9 @@ class ConvBiasReluFunction(Function):
         Cout, _, k, _ = w.shape
         y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
         L = _lib.load()
-        _lib.check(L.g2s_conv_bias_act(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cin,
-                                       Cout, H, W, k, PLAIN, 1, 0.0, 1.0, _lib.stream()))
+        with profiled(2.0 * B * Cout * Cin * k * k * H * W, 4.0 * (x.numel() + w.numel() + y.numel())):
+            _lib.check(L.g2s_conv_bias_act(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cin,
+                                           Cout, H, W, k, PLAIN, 1, 0.0, 1.0, _lib.stream()))
         ctx.save_for_backward(w, y)
         return y
 

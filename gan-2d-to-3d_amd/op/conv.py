@@ -17,9 +17,12 @@ def _conv2d_raw(x, w, bias, Cr, M, k, stride, pad, adjoint, m_major, out_hw, act
         oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     y = torch.empty((B, M, oh, ow), dtype=torch.float32, device=x.device)
     L = _lib.load()
-    _lib.check(L.g2s_conv2d(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W, k,
-                            stride, pad, int(adjoint), int(m_major), oh if adjoint else 0,
-                            ow if adjoint else 0, 1 if act else 0, float(slope), 1.0, _lib.stream()))
+    from gan2shape_amd.modconv import profiled
+    sp = H * W if adjoint else oh * ow  # every (input pixel, tap) pair of the strided side once
+    with profiled(2.0 * B * Cr * M * k * k * sp, 4.0 * (x.numel() + w.numel() + y.numel())):
+        _lib.check(L.g2s_conv2d(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W, k,
+                                stride, pad, int(adjoint), int(m_major), oh if adjoint else 0,
+                                ow if adjoint else 0, 1 if act else 0, float(slope), 1.0, _lib.stream()))
     return y
 
 

@@ -1,4 +1,5 @@
-"""One eager training iteration of each kind (after one warm-up of each) for rocprofv3 --pmc passes."""
+"""The 20-step 7:7:6 cycle of bench.py as eager training iterations (after one warm-up of each kind),
+for the rocprofv3 --pmc passes behind bench.py's roofline.traffic."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,8 +11,12 @@ torch.manual_seed(0)
 tr = Trainer(GAN2Shape, bench.face_config(8), device=dev)
 image, latent = bench.synthetic_sample(tr.model, 1234, dev)
 r = bench.StepRunner(tr, image, latent)
-for rep in range(2):
-    for k in (1, 2, 3):
-        r.run(k)
-        torch.cuda.synchronize()
-        print("done", rep, k, flush=True)
+for k in (1, 2, 3):
+    r.run(k)
+torch.cuda.synchronize()
+torch.ones(3, dtype=torch.int32, device=dev).bitwise_not()  # marker: the counted cycle starts here
+torch.cuda.synchronize()
+for i, k in enumerate(bench.PATTERN):
+    r.run(k)
+    torch.cuda.synchronize()
+    print("done", i, k, flush=True)
