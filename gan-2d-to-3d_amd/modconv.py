@@ -234,34 +234,42 @@ def conv2d(x, w, mode):
     return PlainConvFunction.apply(x, w, mode)
 
 
-class ConvBiasReluFunction(Function):
-    """relu(conv3x3(x, w, padding=1) + bias) for a FROZEN network (no weight / bias gradient): the
-    VGG16 trunk of LPIPS (lpips/pretrained_networks.py:97-135).  Forward is one launch
-    (g2s_conv_bias_act); backward = ReLU mask (g2s_fused_bias_act, act 3 / grad 1 / alpha 0) + the
-    data-gradient GEMM."""
+class ConvBiasActFunction(Function):
+    """gain * leaky_relu(conv(x, w) + bias, alpha) for a FROZEN network (no weight / bias gradient):
+    the VGG16 trunk of LPIPS (conv3x3 + bias + ReLU, lpips/pretrained_networks.py:97-135) and the
+    discriminator's ConvLayer (EqualConv2d + FusedLeakyReLU, stylegan2-pytorch/model.py:630-676).
+    Forward is one launch (g2s_conv_bias_act); backward = activation slope from the saved output
+    (g2s_fused_bias_act, act 3 / grad 1) + the data-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, mode, alpha, gain):
         x, w, bias = x.contiguous(), w.contiguous(), bias.contiguous()
         B, Cin, H, W = x.shape
         Cout, _, k, _ = w.shape
-        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        oh, ow = out_size(H, k, mode), out_size(W, k, mode)
+        y = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device)
         L = _lib.load()
-        with profiled(2.0 * B * Cout * Cin * k * k * H * W, 4.0 * (x.numel() + w.numel() + y.numel())):
+        with profiled(2.0 * B * Cout * Cin * k * k * oh * ow, 4.0 * (x.numel() + w.numel() + y.numel())):
             _lib.check(L.g2s_conv_bias_act(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cin,
-                                           Cout, H, W, k, PLAIN, 1, 0.0, 1.0, _lib.stream()))
+                                           Cout, H, W, k, mode, 1, float(alpha), float(gain), _lib.stream()))
         ctx.save_for_backward(w, y)
+        ctx.cfg = (mode, float(alpha), float(gain))
         return y
 
     @staticmethod
     def backward(ctx, gy):
         w, y = ctx.saved_tensors
+        mode, alpha, gain = ctx.cfg
         if not ctx.needs_input_grad[0]:
-            return None, None, None
+            return None, None, None, None, None, None
         from .plugins import fused
-        g = fused.fused_bias_act(gy.contiguous(), gy.new_empty(0), y, 3, 1, 0.0, 1.0)
-        return modconv_raw(g, w, None, None, PLAIN, 1), None, None
+        g = fused.fused_bias_act(gy.contiguous(), gy.new_empty(0), y, 3, 1, alpha, gain)
+        return modconv_raw(g, w, None, None, mode, 1), None, None, None, None, None
+
+
+def conv_bias_act(x, w, bias, mode=PLAIN, alpha=0.0, gain=1.0):
+    return ConvBiasActFunction.apply(x, w, bias, mode, alpha, gain)
 
 
 def conv_bias_relu(x, w, bias):
-    return ConvBiasReluFunction.apply(x, w, bias)
+    return ConvBiasActFunction.apply(x, w, bias, PLAIN, 0.0, 1.0)

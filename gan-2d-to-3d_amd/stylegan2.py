@@ -22,7 +22,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from .modconv import DOWN2, PLAIN, UP2, conv2d, conv2d_supported, demodulation, modconv
+from .modconv import DOWN2, PLAIN, UP2, conv2d, conv2d_supported, conv_bias_act, demodulation, modconv
 from .op import FusedLeakyReLU, fused_leaky_relu, fused_noise_bias_act, upfirdn2d
 
 
@@ -460,6 +460,20 @@ class ConvLayer(nn.Sequential):
         if activate:
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
+
+    def forward(self, input):
+        conv, act = self[-2], self[-1]
+        # frozen D on the GPU: convolution + bias + leaky-ReLU * sqrt(2) in one launch of the MFMA
+        # kernel instead of conv, then an elementwise pass over the activation
+        if (isinstance(act, FusedLeakyReLU) and isinstance(conv, EqualConv2d) and conv.bias is None
+                and input.is_cuda and not (torch.is_grad_enabled() and
+                                           (conv.weight.requires_grad or act.bias.requires_grad))):
+            x = self[0](input) if len(self) == 3 else input
+            w = conv._w.get(conv.weight, conv.scale)
+            mode = conv2d_supported(x, w, conv.stride, conv.padding)
+            if mode is not None and x.shape[0] * x.shape[2] * x.shape[3] >= 1024:
+                return conv_bias_act(x, w, act.bias, mode, act.negative_slope, act.scale)
+        return super().forward(input)
 
 
 class ResBlock(nn.Module):
