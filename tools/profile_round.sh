@@ -22,4 +22,8 @@ python3 $R/tools/pmc_modconv_traffic.py $(find /tmp/pmc_f -name "*counter_collec
 echo "[5] per-step-kind breakdowns"
 bash $R/tools/profile_kinds.sh "1 2 3"
 cp $R/gpurun_out/kinds/step*.txt $O/
+echo "[6] micro-benchmarks"
+python3 $R/tools/bench_raster.py > $O/raster_microbench.txt 2>&1
+python3 $R/tools/conv_census.py > $O/conv_census.txt 2>&1
+python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 echo done
