@@ -108,6 +108,7 @@ class GAN2Shape(nn.Module):
 
         self._depth_border = None
         self._centers = None
+        self.batch_mean = None  # see get_clamped_depth
         # run the independent D / A / V / L nets as concurrent stream branches (see _fork); off by
         # default: measured slower on MI355X (step 1: 3.45 -> 5.66 ms) — a forked HIP graph pays
         # more for its cross-queue joins than the overlapped launch latencies give back
@@ -121,7 +122,8 @@ class GAN2Shape(nn.Module):
     def depth_net_forward(self, inputs, prior):
         """model.py:88-93, including the (B,H,W) - (1,1,1,1) broadcast to a 4-D depth."""
         depth_raw = self.depth_net(inputs).squeeze(1)
-        depth = depth_raw - depth_raw.view(1, 1, -1).mean(2).view(1, 1, 1, 1)
+        mean = depth_raw.view(1, 1, -1).mean(2) if self.batch_mean is None else self.batch_mean(depth_raw)
+        depth = depth_raw - mean.view(1, 1, 1, 1)
         depth = depth.tanh()
         depth = self.rescale_depth(depth)
         return F.mse_loss(depth[0], prior.detach().expand(depth.size(1), -1, -1)), depth
@@ -139,7 +141,10 @@ class GAN2Shape(nn.Module):
     def get_clamped_depth(self, depth_raw, h, w, clamp_border=True):
         """model.py:337-345: centre over the WHOLE batch, tanh, rescale; the two left/right border
         columns blend towards border_depth with weight 1.02."""
-        depth_centered = depth_raw - depth_raw.view(1, -1).mean(1).view(1, 1, 1)
+        # batch_mean: None = this process holds the whole batch; the joint trainer under data
+        # parallelism sets sharding.global_mean so that the centre stays the WHOLE-batch mean
+        mean = depth_raw.view(1, -1).mean(1) if self.batch_mean is None else self.batch_mean(depth_raw)
+        depth_centered = depth_raw - mean.view(1, 1, 1)
         depth = self.rescale_depth(torch.tanh(depth_centered))
         if clamp_border:
             if self._depth_border is None or self._depth_border.shape[-2:] != (h, w):

@@ -75,7 +75,9 @@ def global_mean(x):
     whole-batch mean of get_clamped_depth (model.py:338) under data parallelism."""
     m = x.mean()
     if dist.is_initialized() and dist.get_world_size() > 1:
-        m = m.clone()
-        dist.all_reduce(m, op=dist.ReduceOp.SUM)
-        m = m / dist.get_world_size()
+        # differentiable all-reduce (its backward all-reduces the incoming gradient): every rank's
+        # loss depends on every rank's depth through the shared centre, and after the gradient
+        # averaging of allreduce_mean_gradients the result is the gradient of the batch-mean loss
+        import torch.distributed.nn.functional as dist_fn
+        m = dist_fn.all_reduce(m.clone(), op=dist.ReduceOp.SUM) / dist.get_world_size()
     return m

@@ -150,6 +150,13 @@ class Trainer():
             losses.append(loss.detach())
         return [float(v) for v in torch.stack(losses).cpu()] if losses else []
 
+    def _sync_and_step(self, optim):
+        """optim.step(), preceded under data parallelism by ONE flat-bucket gradient all-reduce
+        (mean) over the parameters this optimiser owns (sharding.allreduce_mean_gradients)."""
+        from .sharding import allreduce_mean_gradients
+        allreduce_mean_gradients([p for g in optim.param_groups for p in g['params']])
+        optim.step()
+
     @staticmethod
     def default_optimizer(model_list, lr=1e-4, betas=(0.9, 0.999), weight_decay=5e-4,
                           capturable=False):
@@ -161,3 +168,111 @@ class Trainer():
         fused = bool(param_list) and all(p.is_cuda for p in param_list)
         return torch.optim.Adam(param_list, lr=lr, betas=betas, weight_decay=weight_decay,
                                 capturable=capturable, fused=fused)
+
+
+class GeneralizingTrainer2(Trainer):
+    """Joint training over a set of images (trainer.py:338-479, on GeneralizingTrainer :174-335):
+    pre-train the depth net on every image's prior, then per epoch and per batch of images run
+    step 1 on the batch and steps 2 / 3 image by image — one shared model.
+
+    Data parallelism (added; the reference is single-process): with world_size W every batch of
+    `batch_size` images is dealt round-robin to the ranks (batch_size must be a multiple of W), each
+    rank runs the reference's iteration on its images, and every optimiser step is preceded by one
+    flat-bucket gradient all-reduce (mean) over RCCL (`sharding.allreduce_mean_gradients`: step 1
+    A, step 2 E, step 3 L+V+D+A); `get_clamped_depth` / `depth_net_forward` centre the depth by the
+    mean over ALL ranks' images (`sharding.global_mean`).  W = 1 is the reference's loop exactly.
+    W > 1 equals it up to the reference's own `b = 1` slicing in forward_step1 (model.py:96,150:
+    only the first reconstruction of a call enters the losses), which then applies per rank."""
+
+    def __init__(self, model, model_config, **kwargs):
+        super().__init__(model, model_config, **kwargs)
+        self.n_epochs = model_config.get('n_epochs_generalized', 1)
+
+    def _local_batches(self, images_latents, batch_size, shuffle, rank, world_size):
+        if batch_size % world_size:
+            raise ValueError(f"batch_size {batch_size} must be a multiple of world_size {world_size}")
+        loader = DataLoader(images_latents, batch_size=batch_size, shuffle=shuffle,
+                            num_workers=self.n_workers)
+        for images, latents, indices in loader:
+            if len(images) % world_size:
+                raise ValueError(f"{len(images_latents)} images do not fill batches of {batch_size} "
+                                 f"evenly over {world_size} ranks")
+            sel = slice(rank, None, world_size)
+            yield images[sel].to(self.device), latents[sel].to(self.device), [int(i) for i in indices[sel]]
+
+    def fit(self, images_latents, plot_depth_map=False,
+            stages=[{'step1': 1, 'step2': 1, 'step3': 1}] * 2, batch_size=2, shuffle=False,
+            rank=0, world_size=1, **_):
+        from . import sharding
+        if world_size > 1:
+            self.model.batch_mean = sharding.global_mean
+        total_it = 0
+        try:
+            if self.load_dict is None:
+                self.pretrain_on_prior_all(images_latents, batch_size, rank, world_size)
+            for epoch in range(self.n_epochs):
+                for images, latents, indices in self._local_batches(images_latents, batch_size, shuffle,
+                                                                    rank, world_size):
+                    loss = collected = None
+                    for _ in range(stages[0]['step1']):
+                        self.optim_step1.zero_grad()
+                        loss, collected = self.model.forward_step1(images, latents, None)
+                        loss.backward()
+                        self._sync_and_step(self.optim_step1)
+                        total_it += 1
+                    self.history.append((tuple(indices), epoch, 1, None if loss is None else float(loss.detach())))
+                    if collected is None:
+                        continue
+                    normals, lights_a, lights_b, albedos, depths, canon_masks = collected
+                    if not isinstance(canon_masks, list):
+                        canon_masks = [canon_masks]
+                    for bi, index in enumerate(indices):
+                        image, latent = images[bi:bi + 1], latents[bi:bi + 1]
+                        step1_collected = (normals[bi:bi + 1].detach(), lights_a[bi:bi + 1].detach(),
+                                           lights_b[bi:bi + 1].detach(), albedos[bi:bi + 1].detach(),
+                                           depths[bi:bi + 1].detach(), canon_masks[bi])
+                        loss2 = loss3 = step2_collected = None
+                        for _ in range(stages[0]['step2']):
+                            self.optim_step2.zero_grad()
+                            loss2, step2_collected = self.model.forward_step2(
+                                image, latent, step1_collected, n_proj_samples=self.n_proj_samples)
+                            loss2.backward()
+                            self._sync_and_step(self.optim_step2)
+                            total_it += 1
+                        for _ in range(stages[0]['step3'] if step2_collected is not None else 0):
+                            self.optim_step3.zero_grad()
+                            loss3, _c = self.model.forward_step3(image, latent, step2_collected)
+                            loss3.backward()
+                            self._sync_and_step(self.optim_step3)
+                            total_it += 1
+                        self.history.append((index, epoch, 2, None if loss2 is None else float(loss2.detach())))
+                        self.history.append((index, epoch, 3, None if loss3 is None else float(loss3.detach())))
+                if epoch % 20 == 0 and self.save_ckpts and rank == 0:
+                    self.model.save_checkpoint("", epoch, total_it, self.category)
+        finally:
+            self.model.batch_mean = None
+        logging.info('Finished Training')
+        return total_it
+
+    def pretrain_on_prior_all(self, images_latents, batch_size, rank=0, world_size=1):
+        """GeneralizingTrainer.pretrain_on_prior (trainer.py:296-335): one prior per image, then
+        n_epochs_prior passes over the batches with a fresh Adam on the depth net."""
+        optim = Trainer.default_optimizer([self.model.depth_net])
+        priors = {}
+        for image, _, index in DataLoader(images_latents, batch_size=1, shuffle=False):
+            if (int(index[0]) % batch_size) % world_size == rank % world_size or world_size == 1:
+                priors[int(index[0])] = self.prior_generator(image.to(self.device), device=self.device)
+        loss = None
+        for _ in range(self.n_epochs_prior):
+            for images, _latents, indices in self._local_batches(images_latents, batch_size, False,
+                                                                 rank, world_size):
+                for i in indices:
+                    if i not in priors:
+                        item = images_latents[i]
+                        priors[i] = self.prior_generator(item[0].unsqueeze(0).to(self.device), device=self.device)
+                prior = torch.stack([priors[i].reshape(self.image_size, self.image_size) for i in indices])
+                optim.zero_grad()
+                loss, _depth = self.model.depth_net_forward(images, prior)
+                loss.backward()
+                self._sync_and_step(optim)
+        return None if loss is None else float(loss.detach())

@@ -77,3 +77,108 @@ def test_single_process_is_a_noop():
     sharding.allreduce_mean_gradients([p])
     assert torch.equal(p.grad, torch.full((3,), 2.0))
     assert sharding.global_mean(torch.tensor([1.0, 3.0])) == 2.0
+
+
+# ------------------------------------------------------------------ joint trainer (GeneralizingTrainer2)
+class _ToyModel(torch.nn.Module):
+    """CPU stand-in with the model step API the trainers drive (trainer.py:40-48,103-104,147): the
+    real GAN2Shape needs the GPU library; the trainer's batching / collectives do not."""
+
+    def __init__(self, config, debug=False, device="cpu"):
+        super().__init__()
+        torch.manual_seed(7)
+        for name in ("albedo", "offset_encoder", "lighting", "viewpoint", "depth"):
+            setattr(self, f"{name}_net", torch.nn.Linear(12, 4))
+        self.batch_mean = None
+        self.calls = []
+
+    def _feat(self, images):
+        return images.reshape(len(images), -1)[:, :12]
+
+    def depth_net_forward(self, inputs, prior):
+        d = self.depth_net(self._feat(inputs))
+        mean = d.mean() if self.batch_mean is None else self.batch_mean(d)
+        return ((d - mean) ** 2).mean() + 0 * prior.sum(), d
+
+    def forward_step1(self, images, latents, collected, **kw):
+        self.calls.append((1, len(images)))
+        a = self.albedo_net(self._feat(images))
+        d = self.depth_net(self._feat(images)).detach()
+        mean = d.mean() if self.batch_mean is None else self.batch_mean(d)
+        loss = ((a - mean) ** 2).mean()
+        z = torch.zeros(len(images), 1)
+        return loss, (a, z, z, a, d, None if len(images) == 1 else [None] * len(images))
+
+    def forward_step2(self, image, latent, collected, n_proj_samples=8, **kw):
+        self.calls.append((2, len(image)))
+        assert collected[0].shape[0] == 1 and not collected[0].requires_grad
+        e = self.offset_encoder_net(self._feat(image))
+        return (e ** 2).mean() + collected[0].sum() * 0, (e.detach(), e.detach())
+
+    def forward_step3(self, image, latent, collected, **kw):
+        self.calls.append((3, len(image)))
+        out = sum(getattr(self, f"{n}_net")(self._feat(image)).mean() for n in ("lighting", "viewpoint", "depth", "albedo"))
+        return (out - collected[0].mean()) ** 2, None
+
+
+def _toy_data(n=4):
+    g = torch.Generator().manual_seed(3)
+    return [(torch.randn(3, 16, 16, generator=g), torch.randn(8, generator=g), i) for i in range(n)]
+
+
+_TOY_CFG = {"image_size": 16, "category": "face", "n_proj_samples": 2, "n_epochs_prior": 2,
+            "n_epochs_generalized": 2, "prior_name": "ellipsoid"}
+
+
+def _joint_worker(rank, world, port, q, stages):
+    from gan2shape_amd.trainer import GeneralizingTrainer2
+    if world > 1:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                          MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        sharding.init_distributed("gloo")
+    t = GeneralizingTrainer2(_ToyModel, dict(_TOY_CFG), device="cpu")
+    n = t.fit(_toy_data(), stages=stages, batch_size=2, rank=rank, world_size=world)
+    flat = torch.cat([p.detach().reshape(-1) for p in t.model.parameters()])
+    q.put((rank, n, flat.tolist(), list(t.model.calls)))  # plain lists: no shared-memory handles
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run_joint(world, stages):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_joint_worker, args=(r, world, port, q, stages)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=100) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    return [(r, n, torch.tensor(flat), calls) for r, n, flat, calls in res]
+
+
+@pytest.mark.timeout(180)
+def test_joint_trainer_single_process_follows_reference_loop():
+    stages = [{"step1": 2, "step2": 1, "step3": 3}]
+    (_, n, _, calls), = _run_joint(1, stages)
+    # 2 epochs x 2 batches of 2 images: step 1 on the batch, then per image step 2 and step 3
+    per_batch = [(1, 2)] * 2 + ([(2, 1)] * 1 + [(3, 1)] * 3) * 2
+    assert calls == per_batch * 4
+    assert n == len(calls)
+
+
+@pytest.mark.timeout(180)
+def test_joint_trainer_data_parallel_matches_single_process():
+    """Step 1 (batch-mean loss, whole-batch depth mean): two ranks with averaged gradients reproduce
+    the single-process run; with steps 2 / 3 the ranks still hold identical parameters."""
+    stages = [{"step1": 3, "step2": 0, "step3": 0}]
+    (_, n1, ref, _), = _run_joint(1, stages)
+    res = _run_joint(2, stages)
+    assert [r[1] for r in res] == [n1, n1]
+    for _, _, flat, calls in res:
+        assert all(c == (1, 1) for c in calls)          # each rank sees one image of each batch
+        assert float((flat - ref).abs().max()) < 1e-5
+    res = _run_joint(2, [{"step1": 1, "step2": 2, "step3": 1}])
+    assert torch.equal(res[0][2], res[1][2])

@@ -426,3 +426,28 @@ def test_trainer_fit_with_hip_graphs():
     # step 1 is deterministic given the initial weights: the 6th-iteration losses agree
     assert abs(losses[True][0] - losses[False][0]) < 5e-3 * abs(losses[False][0])
     torch.cuda.set_stream(torch.cuda.default_stream(dev))
+
+
+def test_joint_trainer_on_gpu():
+    """GeneralizingTrainer2 (trainer.py:338-479) with the real model: prior pre-training over all
+    images, step 1 on a batch of 2 images, steps 2 / 3 image by image; finite losses, every trained
+    net moves."""
+    import bench
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import GeneralizingTrainer2
+    dev = torch.device("cuda")
+    cfg = bench.face_config(n_proj=2)
+    cfg.update(n_epochs_prior=2, n_epochs_generalized=1)
+    torch.manual_seed(0)
+    t = GeneralizingTrainer2(GAN2Shape, cfg, device=dev)
+    data = []
+    for i in range(2):
+        image, latent = bench.synthetic_sample(t.model, 100 + i, dev)
+        data.append((image[0].cpu(), latent[0].cpu(), i))
+    before = {n: p.detach().clone() for n, p in t.model.named_parameters() if p.requires_grad}
+    n = t.fit(data, stages=[{'step1': 2, 'step2': 1, 'step3': 1}], batch_size=2)
+    assert n == 2 + 2 * (1 + 1)
+    assert all(h[3] is None or math.isfinite(h[3]) for h in t.history) and len(t.history) == 1 + 2 * 2
+    moved = {n.split('.')[0] for n, p in t.model.named_parameters()
+             if n in before and not torch.equal(before[n], p.detach())}
+    assert {'depth_net', 'albedo_net', 'viewpoint_net', 'lighting_net', 'offset_encoder_net'} <= moved
