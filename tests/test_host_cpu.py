@@ -213,3 +213,56 @@ def test_shard_indices_partition():
         shards = [shard_indices(n, r, w) for r in range(w)]
         assert sorted(i for s in shards for i in s) == list(range(n))
         assert shards[0][:2] == [0, w][:len(shards[0][:2])]
+
+
+# ----------------------------------------------------------------------------- dataset format
+def _make_dataset(root):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    os.makedirs(os.path.join(root, "latents"))
+    names = []
+    for i, (w, h) in enumerate([(40, 40), (48, 36), (30, 50)]):
+        name = f"img_{i}.png"
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(os.path.join(root, name))
+        names.append(name)
+        lat = torch.randn(1, 512) if i != 1 else torch.randn(10, 512)
+        obj = lat if i == 0 else ({"latent": lat} if i == 1 else {name: {"latent": lat}})
+        torch.save(obj, os.path.join(root, "latents", f"img_{i}.pt"))
+    with open(os.path.join(root, "list.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+
+
+def test_dataset_formats(tmp_path):
+    """list.txt + latents/*.pt layout of GAN2Shape/dataset.py:8-79 (tensor, {'latent': w} and
+    {name: {'latent': w}} latent files; subsets; [-1, 1] images)."""
+    from gan2shape_amd import dataset
+    root = str(tmp_path)
+    _make_dataset(root)
+    ds = dataset.ImageLatentDataset(root, transform=dataset.default_transform(32))
+    assert len(ds) == 3
+    shapes = [(3, 32, 32), (3, 32, 42), (3, 53, 32)]
+    for i in range(3):
+        image, latent, index = ds[i]
+        assert index == i and tuple(image.shape) == shapes[i]
+        assert image.dtype == torch.float32 and -1 <= float(image.min()) and float(image.max()) <= 1
+        assert tuple(latent.shape) == ((512,) if i != 1 else (10, 512))
+    sub = dataset.ImageLatentDataset(root, transform=dataset.default_transform(32), subset=[2, 0])
+    assert len(sub) == 2 and torch.equal(sub[0][1], ds[2][1]) and torch.equal(sub[1][0], ds[0][0])
+    with pytest.raises(IndexError):
+        dataset.ImageDataset(root, subset=[5])
+
+
+@needs_ref
+def test_dataset_equals_reference(tmp_path):
+    sys.path.insert(0, REF)
+    from GAN2Shape import dataset as ref
+    from gan2shape_amd import dataset
+    root = str(tmp_path)
+    _make_dataset(root)
+    tf = dataset.default_transform(32)
+    a = dataset.ImageLatentDataset(root, transform=tf, subset=[1, 2, 0])
+    b = ref.ImageLatentDataset(root, transform=tf, subset=[1, 2, 0])
+    assert len(a) == len(b)
+    for i in range(len(a)):
+        (ia, la, xa), (ib, lb, xb) = a[i], b[i]
+        assert xa == xb and torch.equal(ia, ib) and torch.equal(la, lb)
