@@ -53,6 +53,24 @@ struct ConvDesc {
     ConvClass cls[4];
 };
 
+// Workgroups are dealt round-robin to the 8 XCDs by their flattened id, and each XCD has its own L2.
+// The M-tiles of one pixel tile all read the same im2col operand: give every XCD a CONTIGUOUS range
+// of logical tiles (M-tile fastest), so that those workgroups share one L2 instead of fetching the
+// operand once per XCD.  Returns the logical tile of this workgroup within its (y, z) grid row.
+__device__ __forceinline__ int xcd_logical_tile() {
+    const int n = gridDim.x, bx = blockIdx.x;
+    const int row = blockIdx.y + gridDim.y * blockIdx.z;
+    const int off = (n * row) & 7;           // XCD of block 0 of this row
+    const int x = (bx + off) & 7;            // XCD this workgroup runs on
+    int start = 0;
+    for (int xx = 0; xx < x; xx++) {         // tiles of this row owned by the XCDs before x
+        const int f = (xx - off) & 7;
+        start += f < n ? (n - f + 7) >> 3 : 0;
+    }
+    const int f = (x - off) & 7;             // first block of this row on XCD x
+    return start + ((bx - f) >> 3);
+}
+
 // K tiles hold WHOLE reduction channels (T taps each): 2 channels x 9 taps = 18 for 3x3, else 16.
 // A thread's elements of a tile then keep the same (channel-in-tile, tap) for the entire K loop,
 // so tap offsets, bounds checks and LDS addresses are computed ONCE; per tile only the channel base
@@ -73,7 +91,7 @@ template <int BM, int BN, int T, bool PARTIAL, bool SCALE>
 __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass &c,
                                              float (&As)[2][KTile<T>::KMAX][BM + 1],
                                              float (&Bs)[2][KTile<T>::KMAX + 1][BN],
-                                             const int (&stab)[25]) {
+                                             const int (&stab)[25], const int tile_id) {
     constexpr int BKT = KTile<T>::BKT, CPT = KTile<T>::CPT, BK_MAX = KTile<T>::KMAX;
     constexpr int WMT = BM / 64, WNT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
     constexpr bool WIDE = (T == 9);              // 9 contiguous taps per (m, channel): 3 x dwordx3
@@ -83,8 +101,8 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
     const int wm = wave >> 1, wn = wave & 1;
     const int Ncls = d.B * c.OH * c.OW;
     const int tiles_m = (d.M + BM - 1) / BM;
-    const int m0 = (blockIdx.x % tiles_m) * BM;
-    const int n0 = (blockIdx.x / tiles_m) * BN;
+    const int m0 = (tile_id % tiles_m) * BM;
+    const int n0 = (tile_id / tiles_m) * BN;
     const int ktiles = (d.Cr + CPT - 1) / CPT;
     const int per = (ktiles + d.splitk - 1) / d.splitk;
     const int kt_begin = blockIdx.y * per;
@@ -316,7 +334,8 @@ __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
     const ConvClass &c = d.cls[blockIdx.z];
     // uniform early exits: smaller parity classes need fewer tiles; empty split-K slices
     const int tiles_m = (d.M + BM - 1) / BM;
-    if ((int)(blockIdx.x / tiles_m) * BN >= d.B * c.OH * c.OW) return;
+    const int tile_id = xcd_logical_tile();
+    if ((int)(tile_id / tiles_m) * BN >= d.B * c.OH * c.OW) return;
     const int ktiles = ktiles_of(d.Cr, c.T);
     const int per = (ktiles + d.splitk - 1) / d.splitk;
     if ((int)blockIdx.y * per >= ktiles) return;
@@ -324,47 +343,47 @@ __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
     __syncthreads();
     const bool scale = d.in_scale != nullptr;
     if constexpr (KMAX == 26) {  // 5x5 (never modulated)
-        modconv_body<BM, BN, 25, true, false>(d, c, As, Bs, stab);
+        modconv_body<BM, BN, 25, true, false>(d, c, As, Bs, stab, tile_id);
         return;
     } else
     switch (c.T) {  // compile-time tap count; no partial-tile checks when the channels fill the K tiles
     case 9:
         if (d.Cr % 2) {
-            if (scale) modconv_body<BM, BN, 9, true, true>(d, c, As, Bs, stab);
-            else modconv_body<BM, BN, 9, true, false>(d, c, As, Bs, stab);
+            if (scale) modconv_body<BM, BN, 9, true, true>(d, c, As, Bs, stab, tile_id);
+            else modconv_body<BM, BN, 9, true, false>(d, c, As, Bs, stab, tile_id);
         } else {
-            if (scale) modconv_body<BM, BN, 9, false, true>(d, c, As, Bs, stab);
-            else modconv_body<BM, BN, 9, false, false>(d, c, As, Bs, stab);
+            if (scale) modconv_body<BM, BN, 9, false, true>(d, c, As, Bs, stab, tile_id);
+            else modconv_body<BM, BN, 9, false, false>(d, c, As, Bs, stab, tile_id);
         }
         break;
     case 16:  // 4x4 (never modulated)
-        modconv_body<BM, BN, 16, true, false>(d, c, As, Bs, stab);
+        modconv_body<BM, BN, 16, true, false>(d, c, As, Bs, stab, tile_id);
         break;
     case 4:
         if (d.Cr % 4) {
-            if (scale) modconv_body<BM, BN, 4, true, true>(d, c, As, Bs, stab);
-            else modconv_body<BM, BN, 4, true, false>(d, c, As, Bs, stab);
+            if (scale) modconv_body<BM, BN, 4, true, true>(d, c, As, Bs, stab, tile_id);
+            else modconv_body<BM, BN, 4, true, false>(d, c, As, Bs, stab, tile_id);
         } else {
-            if (scale) modconv_body<BM, BN, 4, false, true>(d, c, As, Bs, stab);
-            else modconv_body<BM, BN, 4, false, false>(d, c, As, Bs, stab);
+            if (scale) modconv_body<BM, BN, 4, false, true>(d, c, As, Bs, stab, tile_id);
+            else modconv_body<BM, BN, 4, false, false>(d, c, As, Bs, stab, tile_id);
         }
         break;
     case 2:
         if (d.Cr % 8) {
-            if (scale) modconv_body<BM, BN, 2, true, true>(d, c, As, Bs, stab);
-            else modconv_body<BM, BN, 2, true, false>(d, c, As, Bs, stab);
+            if (scale) modconv_body<BM, BN, 2, true, true>(d, c, As, Bs, stab, tile_id);
+            else modconv_body<BM, BN, 2, true, false>(d, c, As, Bs, stab, tile_id);
         } else {
-            if (scale) modconv_body<BM, BN, 2, false, true>(d, c, As, Bs, stab);
-            else modconv_body<BM, BN, 2, false, false>(d, c, As, Bs, stab);
+            if (scale) modconv_body<BM, BN, 2, false, true>(d, c, As, Bs, stab, tile_id);
+            else modconv_body<BM, BN, 2, false, false>(d, c, As, Bs, stab, tile_id);
         }
         break;
     default:
         if (d.Cr % 16) {
-            if (scale) modconv_body<BM, BN, 1, true, true>(d, c, As, Bs, stab);
-            else modconv_body<BM, BN, 1, true, false>(d, c, As, Bs, stab);
+            if (scale) modconv_body<BM, BN, 1, true, true>(d, c, As, Bs, stab, tile_id);
+            else modconv_body<BM, BN, 1, true, false>(d, c, As, Bs, stab, tile_id);
         } else {
-            if (scale) modconv_body<BM, BN, 1, false, true>(d, c, As, Bs, stab);
-            else modconv_body<BM, BN, 1, false, false>(d, c, As, Bs, stab);
+            if (scale) modconv_body<BM, BN, 1, false, true>(d, c, As, Bs, stab, tile_id);
+            else modconv_body<BM, BN, 1, false, false>(d, c, As, Bs, stab, tile_id);
         }
         break;
     }
