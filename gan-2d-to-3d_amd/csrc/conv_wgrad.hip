@@ -109,7 +109,7 @@ using namespace g2s;
 
 extern "C" int g2s_conv2d_wgrad(const float *A, const float *G, float *dw, int B, int Ca, int Cg,
                                 int PH, int PW, int GH, int GW, int k, int stride, int pad,
-                                g2s_stream_t stream) {
+                                int dw_is_zero, g2s_stream_t stream) {
     G2S_REQUIRE(A && G && dw, "NULL pointer argument");
     G2S_REQUIRE(B > 0 && Ca > 0 && Cg > 0 && PH > 0 && PW > 0 && GH > 0 && GW > 0, "sizes must be positive");
     G2S_REQUIRE(k >= 1 && k <= 5 && (stride == 1 || stride == 2) && pad >= 0 && pad < k,
@@ -139,7 +139,7 @@ extern "C" int g2s_conv2d_wgrad(const float *A, const float *G, float *dw, int B
     split = cdiv(p.ktiles, p.per);
     p.atomic = split > 1;
     hipStream_t st = as_stream(stream);
-    if (p.atomic && hipMemsetAsync(dw, 0, (size_t)Ca * p.N * sizeof(float), st) != hipSuccess)
+    if (p.atomic && !dw_is_zero && hipMemsetAsync(dw, 0, (size_t)Ca * p.N * sizeof(float), st) != hipSuccess)
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(dw) failed");
     conv_wgrad_kernel<<<dim3(tiles, split), WG_THREADS, 0, st>>>(p);
     return check_launch("g2s_conv2d_wgrad");

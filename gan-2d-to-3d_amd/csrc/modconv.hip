@@ -425,7 +425,7 @@ struct ConvGeom {
 static int conv_launch(const float *x, const float *w, const float *in_scale, const float *out_scale,
                        const float *bias, int act, float act_alpha, float act_gain, float *y, int B,
                        int Cr, int M, int H, int W, const ConvGeom &g, int tuned_tile, int tuned_splitk,
-                       g2s_stream_t stream) {
+                       g2s_stream_t stream, bool y_is_zero = false) {
     G2S_REQUIRE(x && w && y, "x, w, y must not be NULL");
     G2S_REQUIRE(B > 0 && Cr > 0 && M > 0 && H > 0 && W > 0, "sizes must be positive");
     const int k = g.k, s_ = g.stride, p_ = g.pad, KK = k * k;
@@ -538,7 +538,7 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
         d.act = 0;
     }
     d.splitk = splitk;
-    if (splitk > 1 || holes) {
+    if ((splitk > 1 || holes) && !y_is_zero) {
         if (hipMemsetAsync(y, 0, (size_t)B * d.M * d.OHf * d.OWf * sizeof(float), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
     }
@@ -607,8 +607,10 @@ extern "C" int g2s_conv_bias_act(const float *x, const float *w, const float *bi
 
 extern "C" int g2s_conv2d(const float *x, const float *w, const float *bias, float *y, int B, int Cr,
                           int M, int H, int W, int k, int stride, int pad, int adjoint, int w_m_major,
-                          int out_h, int out_w, int act, float alpha, float gain, g2s_stream_t stream) {
+                          int out_h, int out_w, int act, float alpha, float gain, int y_is_zero,
+                          g2s_stream_t stream) {
     G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
     ConvGeom g{k, stride, pad, adjoint ? 1 : 0, w_m_major ? 1 : 0, adjoint ? out_h : 0, adjoint ? out_w : 0};
-    return conv_launch(x, w, nullptr, nullptr, bias, act, alpha, gain, y, B, Cr, M, H, W, g, -1, -1, stream);
+    return conv_launch(x, w, nullptr, nullptr, bias, act, alpha, gain, y, B, Cr, M, H, W, g, -1, -1, stream,
+                       y_is_zero != 0);
 }

@@ -18,6 +18,22 @@ def run_fused(mods, x):
     from .op import conv as gconv
     from .op.groupnorm import groupnorm_act, supported as gn_supported
     mods = list(mods)
+    # one cleared arena for the convolution outputs of this pass (see PassArena): sized by walking
+    # the spatial sizes through the module list
+    total, (H, W) = 0, (x.shape[2], x.shape[3])
+    for m in mods:
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            H, W = gconv.conv_out_hw(m, H, W)
+            n = x.shape[0] * m.out_channels * H * W
+            if n <= gconv.PassArena.LIMIT:
+                total += gconv.PassArena._pad(n)
+        elif isinstance(m, nn.Upsample):
+            H, W = int(H * m.scale_factor), int(W * m.scale_factor)
+        elif isinstance(m, (nn.AvgPool2d, nn.MaxPool2d)):
+            H, W = H // 2, W // 2
+        elif not isinstance(m, (nn.GroupNorm, nn.ReLU, nn.LeakyReLU, nn.Tanh, nn.Sigmoid)):
+            break  # unknown shape rule: later outputs simply keep their own allocation
+    arena = gconv.PassArena(x.device, total)
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -28,7 +44,7 @@ def run_fused(mods, x):
         elif isinstance(nxt, nn.ReLU):
             slope = 0.0
         if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and gconv.supported(m, x):
-            x = gconv.conv_module(m, x, slope)
+            x = gconv.conv_module(m, x, slope, arena)
             i += 2 if slope is not None else 1
         elif isinstance(m, nn.GroupNorm) and slope is not None and gn_supported(x):
             x = groupnorm_act(x, m.weight, m.bias, m.num_groups, m.eps, True, slope)

@@ -9,30 +9,93 @@ from torch.autograd import Function
 from gan2shape_amd import lib as _lib
 
 
-def _conv2d_raw(x, w, bias, Cr, M, k, stride, pad, adjoint, m_major, out_hw, act, slope):
+class PassArena:
+    """Zero-filled scratch for the convolution outputs of ONE pass through a small net (forward
+    outputs; data- and weight-gradients of its backward).  The split-K paths of g2s_conv2d /
+    g2s_conv2d_wgrad add partial sums into a cleared output: instead of one clear per launch
+    (~100 tiny fill kernels per training iteration of the depth / albedo / viewpoint / lighting
+    nets) the pass clears one arena and hands out slices.  Slices are ordinary views of a freshly
+    allocated tensor (owned by the autograd graph of this pass), so nothing outlives its data; a
+    request that does not fit gets its own tensor and the library's own clear."""
+
+    LIMIT = 1 << 20  # elements: larger outputs keep their own allocation
+
+    def __init__(self, device, fwd_elems):
+        self.device = device
+        self.fwd = torch.zeros(fwd_elems, dtype=torch.float32, device=device) if fwd_elems else None
+        self.fwd_off = 0
+        self.bwd_need = 0
+        self.bwd = None
+        self.bwd_off = 0
+
+    @staticmethod
+    def _pad(n):
+        return (n + 63) & ~63
+
+    def take_fwd(self, shape):
+        n = 1
+        for d in shape:
+            n *= d
+        if self.fwd is None or n > self.LIMIT or self.fwd_off + n > self.fwd.numel():
+            return None
+        v = self.fwd[self.fwd_off:self.fwd_off + n].view(shape)
+        self.fwd_off += self._pad(n)
+        return v
+
+    def reserve_bwd(self, n):
+        if n <= self.LIMIT:
+            self.bwd_need += self._pad(n)
+
+    def take_bwd(self, shape):
+        n = 1
+        for d in shape:
+            n *= d
+        if n > self.LIMIT or self.bwd_need == 0:
+            return None
+        if self.bwd is None:  # first gradient of this pass: one clear for all of them
+            self.bwd = torch.zeros(self.bwd_need, dtype=torch.float32, device=self.device)
+        if self.bwd_off + n > self.bwd.numel():
+            return None       # e.g. a second backward through the same graph
+        v = self.bwd[self.bwd_off:self.bwd_off + n].view(shape)
+        self.bwd_off += self._pad(n)
+        return v
+
+
+def conv_out_hw(mod, H, W):
+    k, s, p = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+    if isinstance(mod, torch.nn.ConvTranspose2d):
+        return (H - 1) * s - 2 * p + k, (W - 1) * s - 2 * p + k
+    return (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+
+
+def _conv2d_raw(x, w, bias, Cr, M, k, stride, pad, adjoint, m_major, out_hw, act, slope, out=None):
     B, _, H, W = x.shape
     if adjoint:
         oh, ow = out_hw if out_hw else ((H - 1) * stride - 2 * pad + k, (W - 1) * stride - 2 * pad + k)
     else:
         oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    y = torch.empty((B, M, oh, ow), dtype=torch.float32, device=x.device)
+    zeroed = out is not None
+    y = out if zeroed else torch.empty((B, M, oh, ow), dtype=torch.float32, device=x.device)
+    assert tuple(y.shape) == (B, M, oh, ow)
     L = _lib.load()
     from gan2shape_amd.modconv import profiled
     sp = H * W if adjoint else oh * ow  # every (input pixel, tap) pair of the strided side once
     with profiled(2.0 * B * Cr * M * k * k * sp, 4.0 * (x.numel() + w.numel() + y.numel())):
         _lib.check(L.g2s_conv2d(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W, k,
                                 stride, pad, int(adjoint), int(m_major), oh if adjoint else 0,
-                                ow if adjoint else 0, 1 if act else 0, float(slope), 1.0, _lib.stream()))
+                                ow if adjoint else 0, 1 if act else 0, float(slope), 1.0, int(zeroed),
+                                _lib.stream()))
     return y
 
 
-def _wgrad(A, G, k, stride, pad):
+def _wgrad(A, G, k, stride, pad, out=None):
     B, Ca, PH, PW = A.shape
     _, Cg, GH, GW = G.shape
-    dw = torch.empty((Ca, Cg, k, k), dtype=torch.float32, device=A.device)
+    zeroed = out is not None
+    dw = out if zeroed else torch.empty((Ca, Cg, k, k), dtype=torch.float32, device=A.device)
     L = _lib.load()
     _lib.check(L.g2s_conv2d_wgrad(_lib.ptr(A), _lib.ptr(G), _lib.ptr(dw), B, Ca, Cg, PH, PW, GH, GW, k,
-                                  stride, pad, _lib.stream()))
+                                  stride, pad, int(zeroed), _lib.stream()))
     return dw
 
 
@@ -42,7 +105,7 @@ class ConvFunction(Function):
     slope is not None (0 = ReLU)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, transposed, slope):
+    def forward(ctx, x, w, bias, stride, pad, transposed, slope, arena=None):
         _lib.require_cuda(x, w, bias)
         if x.dtype != torch.float32 or w.dtype != torch.float32:
             raise RuntimeError("conv: float32 only")
@@ -52,10 +115,23 @@ class ConvFunction(Function):
         if x.shape[1] != cin:
             raise RuntimeError(f"conv: input has {x.shape[1]} channels, weight expects {cin}")
         b = None if bias is None else bias.contiguous()
+        out = None
+        if arena is not None:
+            H, W = x.shape[2], x.shape[3]
+            if transposed:
+                oh, ow = (H - 1) * stride - 2 * pad + k, (W - 1) * stride - 2 * pad + k
+            else:
+                oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+            out = arena.take_fwd((x.shape[0], cout, oh, ow))
+            if ctx.needs_input_grad[0]:
+                arena.reserve_bwd(x.numel())
+            if ctx.needs_input_grad[1]:
+                arena.reserve_bwd(w.numel())
         y = _conv2d_raw(x, w, b, cin, cout, k, stride, pad, transposed, not transposed, None,
-                        slope is not None, slope or 0.0)
+                        slope is not None, slope or 0.0, out=out)
         ctx.save_for_backward(x, w, y if slope is not None else None)
         ctx.cfg = (stride, pad, transposed, slope, bias is not None)
+        ctx.arena = arena
         return y
 
     @staticmethod
@@ -69,14 +145,17 @@ class ConvFunction(Function):
             gy = fused.fused_bias_act(gy, gy.new_empty(0), y, 3, 1, float(slope), 1.0)
         cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
         gx = gw = gb = None
+        arena = ctx.arena
         if ctx.needs_input_grad[0]:
+            out = None if arena is None else arena.take_bwd(tuple(x.shape))
             gx = _conv2d_raw(gy, w, None, cout, cin, k, stride, pad, not transposed, transposed,
-                             (x.shape[2], x.shape[3]), False, 0.0)
+                             (x.shape[2], x.shape[3]), False, 0.0, out=out)
         if ctx.needs_input_grad[1]:
-            gw = _wgrad(x, gy, k, stride, pad) if transposed else _wgrad(gy, x, k, stride, pad)
+            out = None if arena is None else arena.take_bwd(tuple(w.shape))
+            gw = _wgrad(x, gy, k, stride, pad, out) if transposed else _wgrad(gy, x, k, stride, pad, out)
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 def supported(mod, x):
@@ -91,7 +170,8 @@ def supported(mod, x):
             and x.shape[2] + 2 * mod.padding[0] >= k[0] and x.shape[3] + 2 * mod.padding[0] >= k[0])
 
 
-def conv_module(mod, x, slope=None):
+def conv_module(mod, x, slope=None, arena=None):
     """Run nn.Conv2d / nn.ConvTranspose2d `mod` (its parameters, stride, padding) on libg2s.so."""
     transposed = isinstance(mod, torch.nn.ConvTranspose2d)
-    return ConvFunction.apply(x, mod.weight, mod.bias, mod.stride[0], mod.padding[0], transposed, slope)
+    return ConvFunction.apply(x, mod.weight, mod.bias, mod.stride[0], mod.padding[0], transposed, slope,
+                              arena)

@@ -163,12 +163,14 @@ int g2s_conv_bias_act(const float *x, const float *w, const float *bias, float *
  * g2s_conv2d_wgrad: dw[a,g,ky,kx] = sum_{b,py,px} A[b,a,py,px] * G[b,g,py*s+ky-p,px*s+kx-p]
  *   (zero outside G), A [B,Ca,PH,PW], G [B,Cg,GH,GW], dw [Ca,Cg,k,k] fully overwritten.
  *   Conv2d weight gradient: A = grad_out, G = input; ConvTranspose2d: A = input, G = grad_out.
- *   Summation over pixels is split over workgroups and added with float atomics. */
+ *   Summation over pixels is split over workgroups and added with float atomics.
+ * y_is_zero / dw_is_zero != 0: the caller hands over zero-filled outputs (e.g. slices of one cleared
+ *   arena per network pass), so the split-K paths skip their own clear of the output. */
 int g2s_conv2d(const float *x, const float *w, const float *bias, float *y, int B, int Cr, int M, int H,
                int W, int k, int stride, int pad, int adjoint, int w_m_major, int out_h, int out_w,
-               int act, float alpha, float gain, g2s_stream_t stream);
+               int act, float alpha, float gain, int y_is_zero, g2s_stream_t stream);
 int g2s_conv2d_wgrad(const float *A, const float *G, float *dw, int B, int Ca, int Cg, int PH, int PW,
-                     int GH, int GW, int k, int stride, int pad, g2s_stream_t stream);
+                     int GH, int GW, int k, int stride, int pad, int dw_is_zero, g2s_stream_t stream);
 
 /* Tuning hook (tools/tune_modconv.py): force the tile configuration (0: 128x128, 1: 128x64,
  * 2: 64x64 output channels x pixels) and/or the split-K factor of the calling thread's following
