@@ -30,21 +30,23 @@ template <typename T> __device__ __forceinline__ void stf(T *p, float v);
 template <> __device__ __forceinline__ void stf<float>(float *p, float v) { *p = v; }
 template <> __device__ __forceinline__ void stf<__half>(__half *p, float v) { *p = __float2half(v); }
 
-constexpr int TW = 32, TH = 32;  // output tile; block = (32, 8), 4 rows per lane
-
+// Output tile TWX x TH per workgroup of 256 threads, block = (TW, 256 / TW): 32 x 32 for small maps;
+// 64 x 16 / 128 x 16 for wider ones (whole rows: input rows are read as long contiguous runs);
+// TWX = 160 with TW = 128 covers 129..160-wide outputs (the discriminator's 129 x 129 blur) in one
+// tile per row band — lanes loop over x, only the first few take the second turn.
 // UP, DOWN apply to both axes; KH x KW <= 4x4 compile-time taps.
-template <typename T, int UP, int DOWN, int KH, int KW>
+template <typename T, int UP, int DOWN, int KH, int KW, int TW, int TH, int TWX = TW>
 __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T *__restrict__ x,
                                                        const float *__restrict__ k,
                                                        T *__restrict__ y, UpfirParams p) {
     constexpr int IN_H = ((TH - 1) * DOWN + KH - 1) / UP + 2;
-    constexpr int IN_W = ((TW - 1) * DOWN + KW - 1) / UP + 2;
+    constexpr int IN_W = ((TWX - 1) * DOWN + KW - 1) / UP + 2;
     __shared__ float sx[IN_H][IN_W + 1];
     __shared__ float sk[KH][KW];  // flipped taps
 
-    const int tid = threadIdx.y * 32 + threadIdx.x;
-    const int tiles_x = (p.out_w + TW - 1) / TW;
-    const int tile_x0 = (blockIdx.x % tiles_x) * TW;
+    const int tid = threadIdx.y * TW + threadIdx.x;
+    const int tiles_x = (p.out_w + TWX - 1) / TWX;
+    const int tile_x0 = (blockIdx.x % tiles_x) * TWX;
     const int tile_y0 = (blockIdx.x / tiles_x) * TH;
     if (tid < KH * KW) {
         const int ky = tid / KW, kx = tid % KW;
@@ -54,18 +56,68 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T *__restrict__ x,
     const int in_y0 = floor_div(tile_y0 * DOWN - p.pad_y0 + UP - 1, UP);
     const int in_x0 = floor_div(tile_x0 * DOWN - p.pad_x0 + UP - 1, UP);
 
-    for (int m = blockIdx.y; m < p.major; m += gridDim.y) {
+    // this thread's slots of the staged input footprint: plane-independent offsets (-1 = outside the
+    // image -> 0); the next plane's samples are fetched into registers while the current one is filtered
+    constexpr int NE = (IN_H * IN_W + 255) / 256;
+    int soff[NE];
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const int i = tid + e * 256;
+        const int ry = i / IN_W, rx = i % IN_W;
+        const int iy = in_y0 + ry, ix = in_x0 + rx;
+        soff[e] = (i < IN_H * IN_W && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) ? iy * p.in_w + ix : -1;
+    }
+    float pre[NE];
+    auto fetch = [&](int m) {
         const T *xm = x + (size_t)m * p.in_h * p.in_w;
+#pragma unroll
+        for (int e = 0; e < NE; e++) pre[e] = soff[e] >= 0 ? ldf<T>(xm + soff[e]) : 0.0f;
+    };
+    if ((int)blockIdx.y < p.major) fetch(blockIdx.y);
+    for (int m = blockIdx.y; m < p.major; m += gridDim.y) {
         __syncthreads();
-        for (int i = tid; i < IN_H * IN_W; i += 256) {
-            const int ry = i / IN_W, rx = i % IN_W;
-            const int iy = in_y0 + ry, ix = in_x0 + rx;
-            float v = 0.0f;
-            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = ldf<T>(xm + (size_t)iy * p.in_w + ix);
-            sx[ry][rx] = v;
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const int i = tid + e * 256;
+            if (i < IN_H * IN_W) sx[i / IN_W][i % IN_W] = pre[e];
         }
         __syncthreads();
-        const int ox = tile_x0 + threadIdx.x;
+        if (m + (int)gridDim.y < p.major) fetch(m + gridDim.y);
+        for (int ox = tile_x0 + threadIdx.x; ox < tile_x0 + TWX; ox += TW) {
+        if constexpr (UP == 1) {
+            // strips of 4 consecutive output rows per thread: the (3*DOWN + KH) x KW input window is
+            // read from LDS once into registers (7 reads per output for the 4x4 blur instead of
+            // 16 + 16 tap reads), taps live in registers
+            constexpr int ROWS = 3 * DOWN + KH, STRIPS = TH / (4 * (256 / TW));
+            static_assert(STRIPS >= 1 && STRIPS * 4 * (256 / TW) == TH, "tile shape");
+            float kr[KH][KW];
+#pragma unroll
+            for (int a = 0; a < KH; a++)
+#pragma unroll
+                for (int b = 0; b < KW; b++) kr[a][b] = sk[a][b];
+#pragma unroll
+            for (int sp = 0; sp < STRIPS; sp++) {
+            const int oy0 = tile_y0 + (threadIdx.y * STRIPS + sp) * 4;
+            const int ry0 = oy0 * DOWN - p.pad_y0 - in_y0, rx0 = ox * DOWN - p.pad_x0 - in_x0;
+            if (ox < p.out_w && oy0 < p.out_h) {
+                float win[ROWS][KW];
+#pragma unroll
+                for (int j = 0; j < ROWS; j++)
+#pragma unroll
+                    for (int i = 0; i < KW; i++) win[j][i] = sx[ry0 + j][rx0 + i];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int ky = 0; ky < KH; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < KW; kx++) acc += win[r * DOWN + ky][kx] * kr[ky][kx];
+                    if (oy0 + r < p.out_h) stf<T>(y + ((size_t)m * p.out_h + oy0 + r) * p.out_w + ox, acc);
+                }
+            }
+            }
+        } else {
+            static_assert(UP == 1 || (TW == 32 && TH == 32), "the up-sampling path uses 32 x 32 tiles");
 #pragma unroll
         for (int r = 0; r < TH / 8; r++) {
             const int oy = tile_y0 + threadIdx.y + 8 * r;
@@ -85,6 +137,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T *__restrict__ x,
                     if (ky < KH && kx < KW) acc += sx[ry0 + j][rx0 + i] * sk[ky][kx];
                 }
             stf<T>(y + ((size_t)m * p.out_h + oy) * p.out_w + ox, acc);
+        }
+        }
         }
     }
 }
@@ -118,9 +172,27 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(const T *__restrict__ x
 
 template <typename T, int UP, int DOWN, int KH, int KW>
 static void launch_tiled(const T *x, const float *k, T *y, const UpfirParams &p, hipStream_t st) {
-    const int tiles = cdiv(p.out_w, TW) * cdiv(p.out_h, TH);
-    const int gy = std::min(p.major, std::max(1, 8192 / tiles));
-    upfirdn2d_tiled<T, UP, DOWN, KH, KW><<<dim3(tiles, gy), dim3(32, 8), 0, st>>>(x, k, y, p);
+    if (UP == 1 && p.out_w > 128 && p.out_w <= 160) {
+        constexpr int TW = 128, TH = 16, TWX = 160;
+        const int tiles = cdiv(p.out_w, TWX) * cdiv(p.out_h, TH);
+        const int gy = std::min(p.major, std::max(1, 2048 / tiles));
+        upfirdn2d_tiled<T, UP == 1 ? UP : 1, DOWN, KH, KW, TW, TH, TWX><<<dim3(tiles, gy), dim3(TW, 256 / TW), 0, st>>>(x, k, y, p);
+    } else if (UP == 1 && p.out_w >= 96) {
+        constexpr int TW = 128, TH = 16;
+        const int tiles = cdiv(p.out_w, TW) * cdiv(p.out_h, TH);
+        const int gy = std::min(p.major, std::max(1, 2048 / tiles));
+        upfirdn2d_tiled<T, UP == 1 ? UP : 1, DOWN, KH, KW, TW, TH><<<dim3(tiles, gy), dim3(TW, 256 / TW), 0, st>>>(x, k, y, p);
+    } else if (UP == 1 && p.out_w >= 48) {
+        constexpr int TW = 64, TH = 16;
+        const int tiles = cdiv(p.out_w, TW) * cdiv(p.out_h, TH);
+        const int gy = std::min(p.major, std::max(1, 2048 / tiles));
+        upfirdn2d_tiled<T, UP == 1 ? UP : 1, DOWN, KH, KW, TW, TH><<<dim3(tiles, gy), dim3(TW, 256 / TW), 0, st>>>(x, k, y, p);
+    } else {
+        constexpr int TW = 32, TH = 32;
+        const int tiles = cdiv(p.out_w, TW) * cdiv(p.out_h, TH);
+        const int gy = std::min(p.major, std::max(1, 2048 / tiles));
+        upfirdn2d_tiled<T, UP, DOWN, KH, KW, TW, TH><<<dim3(tiles, gy), dim3(TW, 256 / TW), 0, st>>>(x, k, y, p);
+    }
 }
 
 template <typename T>
