@@ -164,6 +164,14 @@ class ScaledLeakyReLU(nn.Module):
         return F.leaky_relu(input, negative_slope=self.negative_slope) * math.sqrt(2)
 
 
+class PreStyle:
+    """A modulation already applied: s = modulation(style) [B, Cin], computed for several layers at
+    once by Generator._batched_styles and handed to ModulatedConv2d.forward in place of the style."""
+
+    def __init__(self, s):
+        self.s = s
+
+
 class ModulatedConv2d(nn.Module):
     """model.py:195-291, input-scaling formulation on g2s_modconv."""
 
@@ -212,7 +220,7 @@ class ModulatedConv2d(nn.Module):
         return w, self._wsq
 
     def forward(self, input, style):
-        s = self.modulation(style)                      # [B, Cin]   (model.py:253)
+        s = style.s if isinstance(style, PreStyle) else self.modulation(style)  # [B, Cin] (model.py:253)
         w, wsq = self._weights()
         demod = None
         if self.demodulate:                             # model.py:256-258
@@ -287,6 +295,21 @@ class ToRGB(nn.Module):
         return out
 
 
+class _StyleRow:
+    """lat[i] of Generator.forward: the latent row, or — in forward order of the layers — the
+    pre-computed modulation of the next layer that asks (each layer indexes exactly once)."""
+
+    def __init__(self, lat, pre):
+        self.lat, self.pre, self.n = lat, pre, 0
+
+    def __getitem__(self, i):
+        if self.pre is None:
+            return self.lat[i]
+        p = self.pre[self.n]
+        self.n += 1
+        return p
+
+
 class NamedTensor(nn.Module):
     """model.py:380-385."""
 
@@ -344,6 +367,44 @@ class Generator(nn.Module):
             in_channel = out_channel
         self.n_latent = self.log_size * 2 - 2
         self.strided_style = StridedStyle(self.n_latent)
+
+    def _style_layers(self):
+        """(ModulatedConv2d, latent index) in forward order (model.py:493-503)."""
+        layers = [(self.conv1.conv, 0), (self.to_rgb1.conv, 1)]
+        i = 1
+        for conv1, conv2, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
+            layers += [(conv1.conv, i), (conv2.conv, i + 1), (to_rgb.conv, i + 2)]
+            i += 2
+        return layers
+
+    def _batched_styles(self, lat):
+        """The 17 modulation linears (EqualLinear(style_dim, Cin), model.py:253) as one baddbmm per
+        distinct Cin instead of 17 addmm launches forward and 34 backward.  Frozen G on the GPU
+        only; returns per-latent-index entries: PreStyle lists are looked up by the caller through
+        _StyleRow."""
+        layers = self._style_layers()
+        mods = [m.modulation for m, _ in layers]
+        if not lat[0].is_cuda or any(m.weight.requires_grad or m.bias.requires_grad for m in mods):
+            return _StyleRow(lat, None)
+        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in mods)
+        if getattr(self, '_style_key', None) != key:
+            groups = {}
+            for n, (m, _) in enumerate(layers):
+                groups.setdefault(m.in_channel, []).append(n)
+            stacks = []
+            with torch.no_grad():
+                for cin, ns in groups.items():
+                    w = torch.stack([mods[n].weight * mods[n].scale for n in ns]).transpose(1, 2).contiguous()
+                    b = torch.stack([mods[n].bias * mods[n].lr_mul for n in ns]).unsqueeze(1).contiguous()
+                    stacks.append((ns, w, b))   # w [L, style_dim, Cin], b [L, 1, Cin]
+            self._style_stacks, self._style_key = stacks, key
+        pre = [None] * len(layers)
+        for ns, w, b in self._style_stacks:
+            x = torch.stack([lat[layers[n][1]] for n in ns])        # [L, B, style_dim]
+            s = torch.baddbmm(b, x, w)                               # [L, B, Cin]
+            for j, n in enumerate(ns):
+                pre[n] = PreStyle(s[j])
+        return _StyleRow(lat, pre)
 
     def make_noise(self):
         device = self.input.input.device
@@ -417,6 +478,7 @@ class Generator(nn.Module):
         # one unbind instead of 2 * n_latent selects: the backward is a single stack, not a
         # zero-fill + copy + add per use (model.py:493-503 indexes latent[:, i] per layer)
         lat = latent.unbind(1)
+        lat = self._batched_styles(lat)
         out = self.conv1(out, lat[0], noise=noise[0])
         skip = self.to_rgb1(out, lat[1])
         i = 1
