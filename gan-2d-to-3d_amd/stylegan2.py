@@ -401,7 +401,7 @@ class Generator(nn.Module):
         pre = [None] * len(layers)
         for ns, w, b in self._style_stacks:
             x = torch.stack([lat[layers[n][1]] for n in ns])        # [L, B, style_dim]
-            s = torch.baddbmm(b, x, w)                               # [L, B, Cin]
+            s = torch.baddbmm(b, x, w).unbind(0)                     # L x [B, Cin]; one stack backward
             for j, n in enumerate(ns):
                 pre[n] = PreStyle(s[j])
         return _StyleRow(lat, pre)
