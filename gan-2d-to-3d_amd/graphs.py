@@ -54,6 +54,10 @@ class GraphedSteps:
         src = self._source(kind)
         if kind > 1 and src is None:
             raise RuntimeError(f"capture step {kind - 1} first")
+        # warm-up (side stream) and capture (capture stream) run backward on different non-default
+        # streams than the parameters' AccumulateGrad nodes were created on: expected here
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
