@@ -309,7 +309,7 @@ def main():
                         "inside the timed region" if args.eager else
                         "eager pass of one 20-step cycle after the graph-replayed timed region")}
         out = {
-            "metric": "GAN2Shape step iters/sec, faces 128x128 b=8",
+            "metric": "GAN2Shape step iters/sec, faces 128\u00d7128 b=8, 1/2/4/8 MI355X",  # BASELINE.json's string
             "value": rate, "unit": "iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
