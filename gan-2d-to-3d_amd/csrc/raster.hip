@@ -523,12 +523,48 @@ __global__ __launch_bounds__(256) void raster_bwd_samples(BwdParams p) {
         }
         if (same && (lane & m)) fn = -1;  // the upper lane of a merged pair retires
     }
-    if (fn < 0) return;
-    for (int k = 0; k < 3; k++) {
-        float *dst = p.gacc + ((size_t)b * p.N + v[k]) * 3;
-        unsafeAtomicAdd(dst + 0, acc[3 * k]);
-        unsafeAtomicAdd(dst + 1, acc[3 * k + 1]);
-        unsafeAtomicAdd(dst + 2, acc[3 * k + 2]);
+    // per-wave LDS hash table keyed by vertex id: neighbouring faces of a tile share vertices, so
+    // the tile's contributions are summed with LDS atomics and each distinct vertex reaches global
+    // memory once (three float atomics) instead of once per merged sample group and corner
+    constexpr int HS = 128;
+    __shared__ int hkey[4][HS];
+    __shared__ float hval[4][HS][3];
+    for (int i2 = lane; i2 < HS; i2 += 64) {
+        hkey[wave][i2] = -1;
+        hval[wave][i2][0] = hval[wave][i2][1] = hval[wave][i2][2] = 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (fn >= 0) {
+        for (int k = 0; k < 3; k++) {
+            int slot = (v[k] * 0x9E3779B1u) >> 25;  // top 7 bits: 0 .. HS-1
+            bool done = false;
+            for (int probe = 0; probe < 16 && !done; probe++) {
+                const int old = atomicCAS(&hkey[wave][slot], -1, v[k]);
+                if (old == -1 || old == v[k]) {
+                    atomicAdd(&hval[wave][slot][0], acc[3 * k]);
+                    atomicAdd(&hval[wave][slot][1], acc[3 * k + 1]);
+                    atomicAdd(&hval[wave][slot][2], acc[3 * k + 2]);
+                    done = true;
+                }
+                slot = (slot + 1) & (HS - 1);
+            }
+            if (!done) {  // crowded table (many distinct vertices in one tile): straight to memory
+                float *dst = p.gacc + ((size_t)b * p.N + v[k]) * 3;
+                unsafeAtomicAdd(dst + 0, acc[3 * k]);
+                unsafeAtomicAdd(dst + 1, acc[3 * k + 1]);
+                unsafeAtomicAdd(dst + 2, acc[3 * k + 2]);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i2 = lane; i2 < HS; i2 += 64) {
+        const int key = hkey[wave][i2];
+        if (key >= 0) {
+            float *dst = p.gacc + ((size_t)b * p.N + key) * 3;
+            unsafeAtomicAdd(dst + 0, hval[wave][i2][0]);
+            unsafeAtomicAdd(dst + 1, hval[wave][i2][1]);
+            unsafeAtomicAdd(dst + 2, hval[wave][i2][2]);
+        }
     }
 }
 
