@@ -266,3 +266,24 @@ def test_dataset_equals_reference(tmp_path):
     for i in range(len(a)):
         (ia, la, xa), (ib, lb, xb) = a[i], b[i]
         assert xa == xb and torch.equal(ia, ib) and torch.equal(la, lb)
+
+
+def test_pass_arena_slices_and_fallbacks():
+    """op/conv.py:PassArena — zero-filled slices per pass; oversize / exhausted requests get None
+    (the caller then allocates and lets the library clear); the backward arena appears on first use."""
+    from gan2shape_amd.op.conv import PassArena
+    a = PassArena(torch.device("cpu"), 64 + 128)
+    v1 = a.take_fwd((2, 5, 2, 3))           # 60 elements -> padded to 64
+    v2 = a.take_fwd((128,))
+    assert v1.shape == (2, 5, 2, 3) and v2.shape == (128,) and float(v1.abs().sum() + v2.abs().sum()) == 0
+    assert v1.data_ptr() + 64 * 4 == v2.data_ptr()          # distinct, 256-byte aligned slices
+    assert a.take_fwd((1,)) is None                          # exhausted
+    assert a.take_fwd((PassArena.LIMIT + 1,)) is None        # too large for the arena
+    assert a.take_bwd((4,)) is None                          # nothing reserved
+    a.reserve_bwd(10)
+    a.reserve_bwd(PassArena.LIMIT + 1)                       # ignored: keeps its own allocation
+    g = a.take_bwd((10,))
+    assert g is not None and a.bwd.numel() == 64 and float(g.abs().sum()) == 0
+    assert a.take_bwd((10,)) is None                         # second backward through the graph
+    empty = PassArena(torch.device("cpu"), 0)
+    assert empty.take_fwd((4,)) is None
