@@ -1,26 +1,18 @@
-"""Image / latent dataset of GAN2Shape (GAN2Shape/dataset.py:8-79): `root/list.txt` names the image
-files, `root/latents/<stem>.pt` holds each image's StyleGAN2 latent.  Same three classes, same item
-layout `(image in [-1, 1] (3,H,W), latent (512,) or (n_latent,512), index)`.
+"""On-disk layout of a GAN2Shape dataset (behaviour of GAN2Shape/dataset.py:8-79): `root/list.txt`
+names the image files, one per line; `root/latents/<stem>.pt` holds each image's StyleGAN2 latent.
+Items are `(image in [-1, 1] of shape (3,H,W), latent (512,) or (n_latent, 512), index)`.
 
-Differences: `list.txt` is read with the csv module (no pandas); latents are loaded with
-`torch.load(weights_only=True)` (tensor or dict-of-tensor files only, nothing is unpickled);
-invalid subsets raise `IndexError` instead of exiting the process.  `default_transform` restates
+Written for this package: `list.txt` is read with the csv module (no pandas); latents are loaded
+with `torch.load(weights_only=True)` (tensor or dict-of-tensor files only — nothing is unpickled);
+an invalid subset raises `IndexError` instead of exiting the process.  `default_transform` restates
 main.py:98-103 (`transforms.Resize(size)` + `ToTensor()`) without torchvision."""
 import csv
-from os import path
+import os
 
 import numpy as np
 import torch
 from PIL import Image
 from torch.utils.data import Dataset
-
-
-def _read_list(root_dir, list_filename, subset):
-    with open(path.join(root_dir, list_filename), newline='') as f:
-        names = [row[0] for row in csv.reader(f) if row]
-    if subset is not None:
-        names = [names[i] for i in subset]  # IndexError on an invalid subset
-    return names
 
 
 def default_transform(image_size):
@@ -39,44 +31,53 @@ def default_transform(image_size):
     return transform
 
 
-class ImageDataset(Dataset):
+class _ListedFiles(Dataset):
+    """The entries of `root/list.txt` (first column), optionally restricted to `subset` indices."""
+
+    def __init__(self, root_dir, list_filename, subset):
+        self.root_dir = root_dir
+        with open(os.path.join(root_dir, list_filename), newline='') as f:
+            names = [row[0] for row in csv.reader(f) if row]
+        self.file_list = names if subset is None else [names[i] for i in subset]
+
+    def __len__(self):
+        return len(self.file_list)
+
+
+class ImageDataset(_ListedFiles):
+    """Images scaled to [-1, 1] (the transform is expected to produce [0, 1])."""
+
     def __init__(self, root_dir, list_filename='list.txt', transform=None, subset=None):
-        self.root_dir = root_dir
+        super().__init__(root_dir, list_filename, subset)
         self.transform = transform
-        self.file_list = _read_list(root_dir, list_filename, subset)
-
-    def __len__(self):
-        return len(self.file_list)
 
     def __getitem__(self, index):
-        with Image.open(path.join(self.root_dir, self.file_list[index])) as image:
-            if self.transform is not None:
-                image = self.transform(image)
-            return image * 2 - 1
+        with Image.open(os.path.join(self.root_dir, self.file_list[index])) as image:
+            data = image if self.transform is None else self.transform(image)
+            return data * 2 - 1
 
 
-class LatentDataset(Dataset):
+class LatentDataset(_ListedFiles):
+    """`latents/<stem>.pt`: a tensor, {'latent': w}, or {name: {'latent': w}} (dataset.py:50-58)."""
+
     def __init__(self, root_dir, list_filename='list.txt', latent_folder='latents', subset=None):
-        self.root_dir = root_dir
+        super().__init__(root_dir, list_filename, subset)
         self.latent_folder = latent_folder
-        self.file_list = _read_list(root_dir, list_filename, subset)
-
-    def __len__(self):
-        return len(self.file_list)
 
     def __getitem__(self, index):
-        latent_file = self.file_list[index].split('.')[0] + '.pt'
-        latent = torch.load(path.join(self.root_dir, self.latent_folder, latent_file),
-                            map_location='cpu', weights_only=True)
-        if isinstance(latent, dict):  # dataset.py:53-56: {'latent': w} or {name: {'latent': w}}
-            if 'latent' not in latent:
-                latent = latent.popitem()[1]
-            latent = latent['latent']
-        latent = latent.detach()
-        return latent.squeeze(0) if latent.dim() == 2 else latent
+        stem = self.file_list[index].split('.')[0]
+        obj = torch.load(os.path.join(self.root_dir, self.latent_folder, stem + '.pt'),
+                         map_location='cpu', weights_only=True)
+        if isinstance(obj, dict):
+            inner = obj if 'latent' in obj else obj.popitem()[1]
+            obj = inner['latent']
+        latent = obj.detach()
+        return latent.squeeze(0) if latent.dim() == 2 else latent   # (1, 512) -> (512,)
 
 
 class ImageLatentDataset(Dataset):
+    """(image, latent, index) triples over the same list."""
+
     def __init__(self, root_dir, list_filename='list.txt', transform=None, latent_folder='latents',
                  subset=None):
         self.image_dataset = ImageDataset(root_dir, list_filename, transform, subset)

@@ -1,6 +1,10 @@
-"""Mirror of GAN2Shape/stylegan2/stylegan2-pytorch/op/fused_act.py (FusedLeakyReLU,
-fused_leaky_relu, :20-92) on top of the `fused` plugin (libg2s.so).  Unlike the reference there
-is no native-PyTorch fallback: CPU tensors raise."""
+"""`FusedLeakyReLU`, `fused_leaky_relu` — the Python op API of
+GAN2Shape/stylegan2/stylegan2-pytorch/op/fused_act.py:74-92 — and `fused_noise_bias_act`, on the
+`fused` plugin (libg2s.so).  No native fallback.
+
+Autograd structure (own): the activation's derivative  g -> g * scale * (out > 0 ? 1 : slope)  is
+linear in g, so ONE function (`_SlopeGate`) serves as the backward of every fused activation and
+as its own backward (double backward comes for free)."""
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -8,107 +12,92 @@ from torch.autograd import Function
 from gan2shape_amd import lib as _lib
 from gan2shape_amd.plugins import fused
 
+_LRELU = 3  # `act` code of fused_bias_act for leaky-ReLU (fused_bias_act_kernel.cu:37-45)
 
-class FusedLeakyReLUFunctionBackward(Function):
-    """fused_act.py:20-49."""
+
+class _SlopeGate(Function):
+    """g * scale * (ref > 0 ? 1 : slope) — fused_bias_act(act=3, grad=1) with `ref` = the forward
+    output."""
 
     @staticmethod
-    def forward(ctx, grad_output, out, negative_slope, scale, need_bias_grad):
+    def forward(ctx, g, ref, slope, scale):
+        ctx.save_for_backward(ref)
+        ctx.gate = (slope, scale)
+        return fused.fused_bias_act(g, g.new_empty(0), ref, _LRELU, 1, slope, scale)
+
+    @staticmethod
+    def backward(ctx, gg):
+        ref, = ctx.saved_tensors
+        return _SlopeGate.apply(gg, ref, *ctx.gate), None, None, None
+
+
+class _BiasLeakyReLU(Function):
+    """scale * leaky_relu(x + bias[c], slope)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, slope, scale):
+        out = fused.fused_bias_act(x, bias, x.new_empty(0), _LRELU, 0, slope, scale)
         ctx.save_for_backward(out)
-        ctx.negative_slope = negative_slope
-        ctx.scale = scale
-        empty = grad_output.new_empty(0)
-        grad_input = fused.fused_bias_act(grad_output, empty, out, 3, 1, negative_slope, scale)
-        if need_bias_grad:
-            dim = [0]
-            if grad_input.dim() > 2:
-                dim += list(range(2, grad_input.dim()))
-            grad_bias = grad_input.sum(dim).detach()
-        else:  # frozen G/D biases (GAN2Shape never optimises them): skip the reduction
-            grad_bias = grad_output.new_empty(0)
-        return grad_input, grad_bias
-
-    @staticmethod
-    def backward(ctx, gradgrad_input, gradgrad_bias):
-        out, = ctx.saved_tensors
-        gradgrad_out = fused.fused_bias_act(gradgrad_input, gradgrad_bias, out, 3, 1,
-                                            ctx.negative_slope, ctx.scale)
-        return gradgrad_out, None, None, None, None
-
-
-class FusedLeakyReLUFunction(Function):
-    """fused_act.py:52-71."""
-
-    @staticmethod
-    def forward(ctx, input, bias, negative_slope, scale):
-        empty = input.new_empty(0)
-        out = fused.fused_bias_act(input, bias, empty, 3, 0, negative_slope, scale)
-        ctx.save_for_backward(out)
-        ctx.negative_slope = negative_slope
-        ctx.scale = scale
+        ctx.gate = (slope, scale)
         return out
 
     @staticmethod
-    def backward(ctx, grad_output):
+    def backward(ctx, gy):
         out, = ctx.saved_tensors
-        need_b = ctx.needs_input_grad[1]
-        grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(
-            grad_output, out, ctx.negative_slope, ctx.scale, need_b)
-        return grad_input, (grad_bias if need_b else None), None, None
+        gx = _SlopeGate.apply(gy, out, *ctx.gate)
+        gb = None
+        if ctx.needs_input_grad[1]:  # frozen G / D biases (GAN2Shape never optimises them) skip this
+            gb = gx.sum([d for d in range(gx.dim()) if d != 1])
+        return gx, gb, None, None
+
+
+def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """sqrt(2) * leaky_relu(input + bias[c], 0.2) by default (fused_act.py:86-92)."""
+    _lib.require_cuda(input, bias)
+    return _BiasLeakyReLU.apply(input, bias, negative_slope, scale)
 
 
 class FusedLeakyReLU(nn.Module):
-    """fused_act.py:74-83."""
+    """fused_act.py:74-83: a learnable per-channel bias followed by the scaled leaky-ReLU."""
 
     def __init__(self, channel, negative_slope=0.2, scale=2 ** 0.5):
         super().__init__()
         self.bias = nn.Parameter(torch.zeros(channel))
-        self.negative_slope = negative_slope
-        self.scale = scale
+        self.negative_slope, self.scale = negative_slope, scale
 
     def forward(self, input):
         return fused_leaky_relu(input, self.bias, self.negative_slope, self.scale)
 
 
-def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
-    """fused_act.py:86-92 — sqrt(2) * leaky_relu(input + bias[c])."""
-    _lib.require_cuda(input, bias)
-    return FusedLeakyReLUFunction.apply(input, bias, negative_slope, scale)
-
-
-class _NoiseBiasAct(Function):
+class _NoiseBiasLeakyReLU(Function):
     """StyledConv tail (stylegan2-pytorch/model.py:349-355) in one pass:
-    lrelu(x + noise_w * noise + bias) * sqrt(2).  Gradient only w.r.t. x (noise weight, noise map
-    and bias belong to the frozen generator)."""
+    scale * leaky_relu(x + noise_w * noise + bias[c]).  Gradient only w.r.t. x (noise weight, noise
+    map and bias belong to the frozen generator)."""
 
     @staticmethod
-    def forward(ctx, x, noise, noise_w, bias, negative_slope, scale):
+    def forward(ctx, x, noise, noise_w, bias, slope, scale):
         x = x.contiguous()
         B, C, H, W = x.shape
-        y = torch.empty_like(x)
-        nz = None if noise is None else noise.contiguous().view(-1)
-        if nz is not None and nz.numel() != H * W:
+        flat_noise = None if noise is None else noise.contiguous().view(-1)
+        if flat_noise is not None and flat_noise.numel() != H * W:
             raise RuntimeError("noise must be one (1,1,H,W) map")
+        y = torch.empty_like(x)
         L = _lib.load()
-        _lib.check(L.g2s_noise_bias_act(_lib.ptr(x), _lib.ptr(nz),
-                                        _lib.ptr(None if nz is None else noise_w.contiguous()),
-                                        _lib.ptr(bias.contiguous()), _lib.ptr(y), B, C, H * W,
-                                        float(negative_slope), float(scale), _lib.stream()))
+        _lib.check(L.g2s_noise_bias_act(
+            _lib.ptr(x), _lib.ptr(flat_noise), _lib.ptr(None if flat_noise is None else noise_w.contiguous()),
+            _lib.ptr(bias.contiguous()), _lib.ptr(y), B, C, H * W, float(slope), float(scale), _lib.stream()))
         ctx.save_for_backward(y)
-        ctx.negative_slope = negative_slope
-        ctx.scale = scale
+        ctx.gate = (slope, scale)
         return y
 
     @staticmethod
-    def backward(ctx, grad_output):
-        out, = ctx.saved_tensors
-        empty = grad_output.new_empty(0)
-        gx = fused.fused_bias_act(grad_output, empty, out, 3, 1, ctx.negative_slope, ctx.scale)
-        return gx, None, None, None, None, None
+    def backward(ctx, gy):
+        y, = ctx.saved_tensors
+        return _SlopeGate.apply(gy, y, *ctx.gate), None, None, None, None, None
 
 
 def fused_noise_bias_act(x, noise, noise_w, bias, negative_slope=0.2, scale=2 ** 0.5):
     _lib.require_cuda(x, bias)
     if x.dtype != torch.float32:
         raise RuntimeError("fused_noise_bias_act: float32 only")
-    return _NoiseBiasAct.apply(x, noise, noise_w, bias, negative_slope, scale)
+    return _NoiseBiasLeakyReLU.apply(x, noise, noise_w, bias, negative_slope, scale)

@@ -1,35 +1,31 @@
-"""Mirror of GAN2Shape/utils.py:12-41 (resize, crop, get_mask_range)."""
+"""Small tensor helpers with the behaviour of GAN2Shape/utils.py:12-41 (resize, crop,
+get_mask_range), written for this package."""
 import torch
 import torch.nn.functional as F
 
 
 def resize(image, size):
-    """bilinear up / area down / identity when sizes are equal (utils.py:12-23)."""
-    dim = image.dim()
-    if dim == 3:
-        image = image.unsqueeze(1)
-    b, _, h, w = image.shape
-    if size[0] > h:
-        image = F.interpolate(image, size, mode='bilinear')
-    elif size[0] < h:
-        image = F.interpolate(image, size, mode='area')
-    if dim == 3:
-        image = image.squeeze(1)
-    return image
+    """Resize the last two dims to `size` = (H, W): bilinear when the target is taller than the
+    source, area (box) averaging when it is shorter, untouched when the heights agree.  A 3-D
+    tensor is treated as a batch of single-channel maps (utils.py:12-23)."""
+    single_channel = image.dim() == 3
+    maps = image[:, None] if single_channel else image
+    src_h = maps.shape[-2]
+    if size[0] != src_h:
+        maps = F.interpolate(maps, size, mode='bilinear' if size[0] > src_h else 'area')
+    return maps[:, 0] if single_channel else maps
 
 
 def crop(tensor, crop_size):
-    size = tensor.size(2)   # assume h=w
-    margin = (size - crop_size) // 2
-    return tensor[:, :, margin:margin + crop_size, margin:margin + crop_size]
+    """Centred square crop of an (N, C, S, S) tensor (utils.py:26-30)."""
+    lo = (tensor.shape[2] - crop_size) // 2
+    hi = lo + crop_size
+    return tensor[:, :, lo:hi, lo:hi]
 
 
 def get_mask_range(mask):
-    h_range = torch.arange(0, mask.size(0))
-    w_range = torch.arange(0, mask.size(1))
-    grid = torch.stack(torch.meshgrid([h_range, w_range], indexing="ij"), 0).float()
-    max_y = torch.max(grid[0, mask])
-    min_y = torch.min(grid[0, mask])
-    max_x = torch.max(grid[1, mask])
-    min_x = torch.min(grid[1, mask])
-    return max_y, min_y, max_x, min_x
+    """(max_y, min_y, max_x, min_x) of the True entries of a 2-D boolean mask, as float scalars
+    (utils.py:33-41)."""
+    rows, cols = torch.nonzero(mask, as_tuple=True)
+    rows, cols = rows.float(), cols.float()
+    return rows.max(), rows.min(), cols.max(), cols.min()
