@@ -177,6 +177,12 @@ class GAN2Shape(nn.Module):
         diffuse_shading, texture = self.get_shading(normal, lighting_a, lighting_b, lighting_d, albedo)
         return lighting_a, lighting_b, diffuse_shading, texture
 
+    @staticmethod
+    def _head(x, n):
+        """x[:n]; the tensor itself when it has exactly n rows (an identity slice would still cost a
+        zero-fill + copy in backward)."""
+        return x if x.shape[0] == n else x[:n]
+
     def _no_grad_if(self, cond):
         return torch.no_grad() if cond else torch.enable_grad()
 
@@ -243,8 +249,9 @@ class GAN2Shape(nn.Module):
         if eval:
             return recon_im, recon_depth
 
-        loss_l1_im = self.photometric_loss(recon_im[:b], images, mask=recon_im_mask[:b])
-        perc_pair = (recon_im[:b] * recon_im_mask[:b], images * recon_im_mask[:b])
+        recon_b, mask_b = self._head(recon_im, b), self._head(recon_im_mask, b)   # model.py:150: b = 1
+        loss_l1_im = self.photometric_loss(recon_b, images, mask=mask_b)
+        perc_pair = (recon_b * mask_b, images * mask_b)
         loss_smooth = self.smooth_loss(depth) + self.smooth_loss(diffuse_shading)
         canon_mask = None if len(images) == 1 else [None] * len(images)
         collected = (normal, lighting_a, lighting_b, albedo, depth, canon_mask)
@@ -353,10 +360,13 @@ class GAN2Shape(nn.Module):
             depth_raw, albedo1, view_all, light_all = self._fork([
                 lambda: self.depth_net(images), lambda: self.albedo_net(images),
                 lambda: self.viewpoint_net(both), lambda: self.lighting_net(both)])
+            # one split each (a single concatenation in backward) instead of two slices (a zero-fill
+            # + copy each)
+            view1, view = view_all.split([1, b])
+            light1, light = light_all.split([1, b])
             step1_loss, collected, perc1 = self.forward_step1(
-                images, None, None, step1=False,
-                _nets=(depth_raw, albedo1, view_all[:1], light_all[:1]), _defer_perc=True)
-            view, light = view_all[1:], light_all[1:]
+                images, None, None, step1=False, _nets=(depth_raw, albedo1, view1, light1),
+                _defer_perc=True)
         else:
             step1_loss, collected = self.forward_step1(images, None, None, step1=False)
             perc1 = None
@@ -376,11 +386,13 @@ class GAN2Shape(nn.Module):
         recon_im = F.grid_sample(texture, grid_2d_from_canon, mode='bilinear',
                                  align_corners=True).clamp(min=-1, max=1)
 
-        loss_l1_im = self.photometric_loss(recon_im[:b], projected_samples, mask=recon_im_mask[:b])
-        pred, target = recon_im[:b] * recon_im_mask[:b], projected_samples * recon_im_mask[:b]
+        recon_b, mask_b = self._head(recon_im, b), self._head(recon_im_mask, b)
+        loss_l1_im = self.photometric_loss(recon_b, projected_samples, mask=mask_b)
+        pred, target = recon_b * mask_b, projected_samples * mask_b
         if perc1 is not None:
             perc = self.perceptual_loss(torch.cat([perc1[0], pred], 0), torch.cat([perc1[1], target], 0))
-            loss_perc_1, loss_perc_im = torch.mean(perc[:1]), torch.mean(perc[1:])
+            perc_1, perc_n = perc.split([1, b])
+            loss_perc_1, loss_perc_im = torch.mean(perc_1), torch.mean(perc_n)
             step1_loss = step1_loss + self.lam_perc * loss_perc_1
         else:
             loss_perc_im = torch.mean(self.perceptual_loss(pred, target))
