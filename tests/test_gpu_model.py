@@ -451,3 +451,54 @@ def test_joint_trainer_on_gpu():
     moved = {n.split('.')[0] for n, p in t.model.named_parameters()
              if n in before and not torch.equal(before[n], p.detach())}
     assert {'depth_net', 'albedo_net', 'viewpoint_net', 'lighting_net', 'offset_encoder_net'} <= moved
+
+
+def _joint_dp_worker(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+    from gan2shape_amd import sharding
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import GeneralizingTrainer2
+    sharding.init_distributed("gloo")      # both ranks share the one GPU of the test box
+    dev = torch.device("cuda", 0)
+    cfg = bench.face_config(n_proj=2)
+    cfg.update(n_epochs_prior=1, n_epochs_generalized=1)
+    torch.manual_seed(0)
+    t = GeneralizingTrainer2(GAN2Shape, cfg, device=dev)
+    data = []
+    for i in range(2):
+        image, latent = bench.synthetic_sample(t.model, 100 + i, dev)
+        data.append((image[0].cpu(), latent[0].cpu(), i))
+    n = t.fit(data, stages=[{'step1': 1, 'step2': 1, 'step3': 1}], batch_size=2, rank=rank, world_size=world)
+    flat = torch.cat([p.detach().reshape(-1).cpu() for nme, p in t.model.named_parameters()
+                      if nme.split('.')[0] in ('depth_net', 'albedo_net', 'viewpoint_net', 'lighting_net',
+                                               'offset_encoder_net')])
+    q.put((rank, n, float(flat.double().sum()), float(flat.double().abs().sum()), bool(torch.isfinite(flat).all())))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_joint_trainer_data_parallel_two_ranks_on_gpu():
+    """GeneralizingTrainer2 with world_size 2 (gloo between two processes on the one GPU): each rank
+    trains its image of the batch, gradients are averaged before every optimiser step, the depth
+    centre is the all-rank mean — both ranks must end with the same parameters."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_joint_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=280) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, s0, a0, ok0), (_, n1, s1, a1, ok1) = res
+    assert ok0 and ok1 and n0 == n1 == 1 + 1 * (1 + 1)
+    assert abs(s0 - s1) <= 1e-6 * a0 and abs(a0 - a1) <= 1e-6 * a0
