@@ -502,3 +502,23 @@ def test_joint_trainer_data_parallel_two_ranks_on_gpu():
     (_, n0, s0, a0, ok0), (_, n1, s1, a1, ok1) = res
     assert ok0 and ok1 and n0 == n1 == 1 + 1 * (1 + 1)
     assert abs(s0 - s1) <= 1e-6 * a0 and abs(a0 - a1) <= 1e-6 * a0
+
+
+@pytest.mark.parametrize("gan_size,cm,prior,n_proj", [(256, 1, "smoothed_box", 4), (512, 2, "ellipsoid", 2)])
+def test_other_baseline_configs_run(gan_size, cm, prior, n_proj):
+    """BASELINE configs 3 / 4 (cat: gan_size 256, smoothed-box prior; car: gan_size 512, channel
+    multiplier 2): G output is area-resized to 128; one prior pre-training step and one iteration of
+    each kind run and give finite losses (plumbing check of the larger generator / discriminator)."""
+    import bench
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import Trainer
+    dev = torch.device("cuda")
+    cfg = bench.face_config(n_proj=n_proj)
+    cfg.update(gan_size=gan_size, channel_multiplier=cm, prior_name=prior, n_epochs_prior=1,
+               category="cat" if gan_size == 256 else "car")
+    torch.manual_seed(0)
+    t = Trainer(GAN2Shape, cfg, device=dev)
+    image, latent = bench.synthetic_sample(t.model, 7, dev)
+    n = t.fit([(image[0].cpu(), latent[0].cpu(), 0)], stages=[{'step1': 1, 'step2': 1, 'step3': 1}])
+    assert n == 3
+    assert all(math.isfinite(h[3]) for h in t.history) and len(t.history) == 3
