@@ -1,6 +1,7 @@
 """GAN2Shape training-step throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 without a launcher: starts
+                                                                 N ranks itself, see self_launch)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (config.workload = "face128_n8"): configs/face.yml restated for the offline box — image
@@ -175,6 +176,35 @@ def cpu_baseline(n_proj):
                       f"custom-kernel share of the iteration only"}
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks of this script through
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) as CHILD processes — this
+    parent never initialises the GPU — and relay rank 0's JSON line.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL on this driver
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out_line in proc.stdout.splitlines():
+        try:
+            if "metric" in json.loads(out_line):
+                line = out_line
+        except ValueError:
+            sys.stderr.write(out_line + "\n")
+    if proc.returncode == 0 and line is None:
+        sys.stderr.write("[bench] the ranks exited without printing a result line\n")
+        return 1
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +217,8 @@ def main():
                     help="analysis only: time a single step kind instead of the 7:7:6 mix")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))   # before anything in this process touches the GPU
     global PATTERN
     if args.only:
         PATTERN = [args.only]

@@ -613,6 +613,16 @@ extern "C" size_t g2s_raster_workspace_bytes(int B, int n_verts, int n_faces, in
     return (size_t)B * ((size_t)n_verts + (size_t)nchunks) * sizeof(float4) + 256;
 }
 
+// g2s_raster_tune: per-thread override of the tile-to-wave mapping (tools/bench_raster.py).
+static thread_local int g_force_waves = 0;
+
+extern "C" int g2s_raster_tune(int waves_per_tile) {
+    G2S_REQUIRE(waves_per_tile == 0 || waves_per_tile == 1 || waves_per_tile == 4,
+                "waves_per_tile must be 0 (built-in choice), 1 or 4");
+    g_force_waves = waves_per_tile;
+    return G2S_OK;
+}
+
 extern "C" int g2s_raster_depth_fwd(const float *verts, const int32_t *faces, int B, int n_verts,
                                     int n_faces, int S, const float *K, float orig_size, int ssaa,
                                     int fill_back, float near_, float far_, float *depth_out,
@@ -650,8 +660,7 @@ extern "C" int g2s_raster_depth_fwd(const float *verts, const int32_t *faces, in
     const int tiles_side = (p.is + TILE - 1) / TILE;
     const int ntiles = tiles_side * tiles_side, wg_side = (tiles_side + 1) / 2;
     // few tiles: all 4 waves of a workgroup on one tile; many tiles: one tile per wave
-    static const char *force = getenv("G2S_RASTER_SPLIT");
-    const bool split = force ? atoi(force) == 4 : (long)ntiles * B <= 4096;
+    const bool split = g_force_waves ? g_force_waves == 4 : (long)ntiles * B <= 4096;
     const dim3 grid = split ? dim3(ntiles, B) : dim3(wg_side * wg_side, B);
     if (!faces) {
         p.nblk_side = implicit_blocks(S);

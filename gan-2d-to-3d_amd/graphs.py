@@ -46,14 +46,25 @@ class GraphedSteps:
     def _source(self, kind):
         return {1: None, 2: self.collected[1], 3: self.collected[2]}[kind]
 
-    def capture(self, kind):
-        """Warm up `warmup` eager iterations on a side stream (library handles, autotuning, lazily
-        built caches), then capture one iteration (recorded, not executed).  Warm-up iterations are
-        real training iterations; callers that count iterations must count them (return value)."""
+    def capture(self, kind, warmup=None):
+        """Warm up `warmup` (default: the constructor's) eager iterations on a side stream (library
+        handles, lazily built caches), then capture one iteration (recorded, not executed).
+        Warm-up iterations are real training iterations; callers that count iterations must count
+        them (return value)."""
+        warmup = self.warmup if warmup is None else int(warmup)
+        if warmup < 1:
+            raise ValueError("capture needs at least one eager warm-up iteration")
         optim = getattr(self.t, f'optim_step{kind}')
         src = self._source(kind)
         if kind > 1 and src is None:
             raise RuntimeError(f"capture step {kind - 1} first")
+        if torch.cuda.current_stream() == torch.cuda.default_stream():
+            # an eager backward on the legacy default stream binds the parameters' AccumulateGrad
+            # nodes to it; capturing the same autograd graph afterwards aborts inside
+            # hipStreamEndCapture (a host segfault, not an exception)
+            raise RuntimeError("GraphedSteps.capture must run with a non-default current stream: call "
+                               "torch.cuda.set_stream(torch.cuda.Stream()) before the first backward "
+                               "of the networks (see graphs.py)")
         # warm-up (side stream) and capture (capture stream) run backward on different non-default
         # streams than the parameters' AccumulateGrad nodes were created on: expected here
         if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
@@ -61,7 +72,7 @@ class GraphedSteps:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(self.warmup):
+            for _ in range(warmup):
                 optim.zero_grad(set_to_none=True)
                 self._iteration(kind, src)
         torch.cuda.current_stream().wait_stream(s)
@@ -72,7 +83,7 @@ class GraphedSteps:
         self.graphs[kind] = g
         self.loss[kind] = loss.detach()
         self.collected[kind] = collected
-        return self.warmup  # iterations actually executed (a stream capture records, it does not run)
+        return warmup  # iterations actually executed (a stream capture records, it does not run)
 
     def run(self, kind):
         """One training iteration of kind `kind` (graph replay)."""

@@ -416,16 +416,22 @@ class GAN2Shape(nn.Module):
                     layer.reset_parameters()
 
     def save_checkpoint(self, img_idx, stage, total_it, category='car'):
-        """model.py:385-408: one .pth per net, {total_it, dataset, model_state_dict}."""
-        now = datetime.datetime.now().strftime("%Y_%m_%d_%H_%M")
-        for net in GAN2Shape.NETS:
-            save_dict = {'total_it': total_it, 'dataset': category,
-                         'model_state_dict': getattr(self, f'{net}_net').state_dict()}
-            filename = self.build_checkpoint_path(self.ckpt_paths['VLADE_nets'], category, net,
-                                                  img_idx, stage, total_it, now)
-            os.makedirs(os.path.dirname(filename), exist_ok=True)
-            with open(filename, 'wb') as f:
-                torch.save(save_dict, f)
+        """model.py:385-408: one .pth per net, {total_it, dataset, model_state_dict}.  Like the
+        reference, a failure (no `our_nets_ckpts` in the config, I/O error) is logged and training
+        continues."""
+        try:
+            now = datetime.datetime.now().strftime("%Y_%m_%d_%H_%M")
+            for net in GAN2Shape.NETS:
+                save_dict = {'total_it': total_it, 'dataset': category,
+                             'model_state_dict': getattr(self, f'{net}_net').state_dict()}
+                filename = self.build_checkpoint_path(self.ckpt_paths['VLADE_nets'], category, net,
+                                                      img_idx, stage, total_it, now)
+                os.makedirs(os.path.dirname(filename), exist_ok=True)
+                with open(filename, 'wb') as f:
+                    torch.save(save_dict, f)
+        except Exception as e:  # noqa: BLE001  (model.py:406-408 swallows everything)
+            logging.error("Error: %s", e)
+            logging.error(">>>Saving failed... continuing training<<<")
 
     def load_from_checkpoints(self, path_base, category):
         paths, indices = self.build_checkpoint_path(path_base, category)

@@ -23,18 +23,13 @@ DEFAULT_NEAR = 0.1
 DEFAULT_FAR = 100.0
 
 
-class _Workspace:
-    """Per-device scratch for the rasterizer (projected vertices + chunk boxes); grown on demand
-    and reused so that render_depth allocates nothing but its outputs."""
-    _bufs = {}
-
-    @classmethod
-    def get(cls, device, nbytes):
-        buf = cls._bufs.get(device)
-        if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            cls._bufs[device] = buf
-        return buf
+def _workspace(device, nbytes):
+    """Rasterizer scratch (projected vertices + chunk boxes), allocated PER CALL: under torch's
+    caching allocator this is a free-list hit, and during a HIP-graph capture the block comes from
+    the graph's private pool and stays reserved for every replay.  (A grown-on-demand shared
+    buffer would be freed when a larger batch arrives while captured graphs still hold its
+    address.)"""
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
 def _regular_grid_faces(S, device):
@@ -74,7 +69,7 @@ class RenderDepthFunction(Function):
             fidx = torch.empty((B, S * ssaa, S * ssaa), dtype=torch.int32, device=verts.device)
             bary = torch.empty((B, S * ssaa, S * ssaa, 3), dtype=torch.float32, device=verts.device)
         ws_bytes = L.g2s_raster_workspace_bytes(B, N, F, S)
-        ws = _Workspace.get(verts.device, ws_bytes)
+        ws = _workspace(verts.device, ws_bytes)
         Kc = (_lib.C.c_float * 9)(*K)
         _lib.check(L.g2s_raster_depth_fwd(_lib.ptr(verts), _lib.ptr(faces), B, N, F, S, Kc,
                                           float(orig_size), ssaa, int(bool(fill_back)),

@@ -127,10 +127,11 @@ class Trainer():
                     if n > 0 and step not in graphed.graphs:
                         if step > 1 and graphed.collected[step - 1] is None:
                             raise RuntimeError(f"step {step} needs at least one step-{step - 1} iteration first")
-                        done = graphed.capture(step)     # the warm-up iterations are real iterations
-                    for _ in range(max(n - done, 0)):
+                        # the warm-up iterations are real iterations: never more than requested
+                        done = graphed.capture(step, warmup=min(graphed.warmup, n))
+                    for _ in range(n - done):
                         graphed.run(step)
-                    total_it += max(n, done) if n > 0 else 0
+                    total_it += n
                     if n > 0:
                         self.history.append((data_index, stage, step, float(graphed.loss[step])))
             if self.save_ckpts:
@@ -179,10 +180,14 @@ class GeneralizingTrainer2(Trainer):
     `batch_size` images is dealt round-robin to the ranks (batch_size must be a multiple of W), each
     rank runs the reference's iteration on its images, and every optimiser step is preceded by one
     flat-bucket gradient all-reduce (mean) over RCCL (`sharding.allreduce_mean_gradients`: step 1
-    A, step 2 E, step 3 L+V+D+A); `get_clamped_depth` / `depth_net_forward` centre the depth by the
-    mean over ALL ranks' images (`sharding.global_mean`).  W = 1 is the reference's loop exactly.
-    W > 1 equals it up to the reference's own `b = 1` slicing in forward_step1 (model.py:96,150:
-    only the first reconstruction of a call enters the losses), which then applies per rank."""
+    A, step 2 E, step 3 L+V+D+A).  Where the reference centres the depth over the whole image
+    batch — prior pre-training (model.py:90) and the batched step 1 (model.py:338) —
+    `get_clamped_depth` / `depth_net_forward` use the mean over ALL ranks' images
+    (`sharding.global_mean`); steps 2 / 3 run image by image in the reference (trainer.py:436-452),
+    so their inner step-1 pass centres each image by its own mean, on every rank as at W = 1.
+    W = 1 is the reference's loop exactly.  W > 1 equals it up to the reference's own `b = 1`
+    slicing in forward_step1 (model.py:96,150: only the first reconstruction of a call enters the
+    losses), which then applies per rank."""
 
     def __init__(self, model, model_config, **kwargs):
         super().__init__(model, model_config, **kwargs)
@@ -204,22 +209,26 @@ class GeneralizingTrainer2(Trainer):
             stages=[{'step1': 1, 'step2': 1, 'step3': 1}] * 2, batch_size=2, shuffle=False,
             rank=0, world_size=1, **_):
         from . import sharding
-        if world_size > 1:
-            self.model.batch_mean = sharding.global_mean
+        # centre of the depth over the WHOLE image batch (all ranks) — only where the reference
+        # itself runs a batch of images through the depth net: prior pre-training and step 1
+        whole_batch = sharding.global_mean if world_size > 1 else None
         total_it = 0
         try:
             if self.load_dict is None:
+                self.model.batch_mean = whole_batch
                 self.pretrain_on_prior_all(images_latents, batch_size, rank, world_size)
             for epoch in range(self.n_epochs):
                 for images, latents, indices in self._local_batches(images_latents, batch_size, shuffle,
                                                                     rank, world_size):
                     loss = collected = None
+                    self.model.batch_mean = whole_batch
                     for _ in range(stages[0]['step1']):
                         self.optim_step1.zero_grad()
                         loss, collected = self.model.forward_step1(images, latents, None)
                         loss.backward()
                         self._sync_and_step(self.optim_step1)
                         total_it += 1
+                    self.model.batch_mean = None   # steps 2 / 3: one image at a time, its own mean
                     self.history.append((tuple(indices), epoch, 1, None if loss is None else float(loss.detach())))
                     if collected is None:
                         continue

@@ -10,7 +10,10 @@
  *     never synchronises, never throws);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *   - returns G2S_OK (0) or a negative error code; g2s_last_error() gives a thread-local message;
- *   - re-entrant; no global mutable state besides the error string.
+ *   - re-entrant; no process-global mutable state.  Thread-local state: the error string and the
+ *     two tuning overrides g2s_modconv_tune / g2s_raster_tune (off by default; they select among
+ *     launch configurations that produce the same results, and only affect the calling thread).
+ *     No environment variable is read.
  */
 #ifndef G2S_H
 #define G2S_H
@@ -67,6 +70,11 @@ int g2s_raster_depth_fwd(const float *verts, const int32_t *faces, int B, int n_
                          float near, float far, float *depth_out, int32_t *face_idx_out,
                          float *bary_out, void *workspace, size_t workspace_bytes,
                          g2s_stream_t stream);
+
+/* Tuning hook (tools/bench_raster.py): waves_per_tile = 4 runs the 4 waves of a workgroup on ONE
+ * 8x8-sample tile, 1 gives every wave its own tile, 0 restores the built-in choice (4 when
+ * B * tiles <= 4096).  Calling thread only; outputs are bit-identical either way. */
+int g2s_raster_tune(int waves_per_tile);
 
 /* Backward of the above w.r.t. verts (neural_renderer backward_depth_map + vertices_to_faces +
  * projection backward).

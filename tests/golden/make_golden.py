@@ -169,6 +169,21 @@ def geometry_golden():
     out["r.invwarped3d"] = np_(R.get_inv_warped_3d_grid(depth))
     out["r.invwarped2d"] = np_(R.get_inv_warped_2d_grid(depth))
     out["r.normal"] = np_(R.get_normal_from_depth(depth))
+    # gradients of <output, cotangent> w.r.t. depth and view through the reference's own autograd
+    # graph (pins the analytic backward kernels of csrc/geometry.hip directly)
+    for name, fn in (("warped3d", R.get_warped_3d_grid), ("invwarped2d", R.get_inv_warped_2d_grid),
+                     ("normal", R.get_normal_from_depth)):
+        d_ = depth.clone().requires_grad_(True)
+        v_ = view.clone().requires_grad_(True)
+        R.set_transform_matrices(v_)
+        y = fn(d_)
+        torch.manual_seed(1)
+        cot = torch.randn_like(y)
+        grads = torch.autograd.grad((y * cot).sum(), (d_, v_), allow_unused=True)
+        out[f"r.{name}.cot"] = np_(cot)
+        out[f"r.{name}.gdepth"] = np_(grads[0])
+        if grads[1] is not None:
+            out[f"r.{name}.gview"] = np_(grads[1])
     np.savez_compressed(os.path.join(OUT, "geometry.npz"), **out)
 
 
@@ -185,6 +200,141 @@ def misc_golden():
     out["resize.x3"] = np_(x[:, 0])
     out["resize.down3"] = np_(gu.resize(x[:, 0], [4, 4]))
     np.savez_compressed(os.path.join(OUT, "misc.npz"), **out)
+
+
+def _import_reference_model():
+    """GAN2Shape/model.py, losses.py, priors.py with import-only placeholders for what is absent
+    offline: `neural_renderer` (external CUDA package) and the `GAN2Shape.stylegan2`
+    package __init__ (it pulls lpips -> IPython / skimage / torchvision); the placeholder exposes
+    the vendored Generator / Discriminator and no PerceptualLoss behaviour.  The pure-torch methods
+    are then called on bare objects; `.cuda()` (hard-coded in model.py:342,351,452-456) is the
+    identity for the duration of the call so that the reference's own lines run on CPU tensors."""
+    sys.path.insert(0, REF)
+    sys.path.insert(0, SG2)
+    sys.modules.setdefault("neural_renderer", types.ModuleType("neural_renderer"))
+    import model as sg2
+    stub = types.ModuleType("GAN2Shape.stylegan2")
+    stub.Generator, stub.Discriminator, stub.PerceptualLoss = sg2.Generator, sg2.Discriminator, None
+    sys.modules["GAN2Shape.stylegan2"] = stub
+    import GAN2Shape.losses as ref_losses
+    import GAN2Shape.model as ref_model
+    import GAN2Shape.priors as ref_priors
+    return ref_model, ref_losses, ref_priors
+
+
+class _cuda_is_identity:
+    def __enter__(self):
+        self.orig = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda t, *a, **k: t
+
+    def __exit__(self, *exc):
+        torch.Tensor.cuda = self.orig
+
+
+def model_golden():
+    """Model-level math of the training step (GAN2Shape/model.py:85-93,330-360,448-470), the three
+    loss classes (losses.py:6-79) and the priors (priors.py:26-107) — outputs of the reference's own
+    code on seeded inputs; the stand-in discriminator / depth net / parsing mask come from
+    tests/model_cases.py and are rebuilt by the tests."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import tempfile
+    import model_cases as mc
+    ref_model, ref_losses, ref_priors = _import_reference_model()
+    out = {}
+    M = object.__new__(ref_model.GAN2Shape)
+    torch.nn.Module.__init__(M)
+    M.max_depth, M.min_depth = 1.1, 0.9
+    M.border_depth = 0.7 * M.max_depth + 0.3 * M.min_depth
+    M.xyz_rotation_range, M.xy_translation_range, M.z_translation_range = 60, 0.1, 0.1
+    M.depth_net = mc.fake_depth_net
+    S = 16
+    with _cuda_is_identity():
+        torch.manual_seed(0)
+        raw = torch.randn(2, S, S)
+        out["m.depth_raw"] = np_(raw)
+        out["m.rescale"] = np_(M.rescale_depth(torch.tanh(raw)))
+        out["m.clamped"] = np_(M.get_clamped_depth(raw, S, S))
+        out["m.clamped_noborder"] = np_(M.get_clamped_depth(raw, S, S, clamp_border=False))
+        view = torch.randn(3, 6)
+        out["m.view"], out["m.view_trans"] = np_(view), np_(M.get_view_transformation(view))
+        light = torch.randn(3, 4) * 0.7
+        la, lb, ld = M.get_lighting_directions(light)
+        out["m.light"], out["m.light_a"], out["m.light_b"], out["m.light_d"] = np_(light), np_(la), np_(lb), np_(ld)
+        normal = torch.randn(3, S, S, 3)
+        normal = normal / normal.norm(dim=3, keepdim=True)
+        albedo = torch.tanh(torch.randn(3, 3, S, S))
+        diffuse, texture = M.get_shading(normal, la, lb, ld, albedo)
+        out["m.normal"], out["m.albedo"] = np_(normal), np_(albedo)
+        out["m.diffuse"], out["m.texture"] = np_(diffuse), np_(texture)
+        # gradients of sum(texture * gt) + sum(diffuse * gd) w.r.t. normal / light / albedo
+        n_, l_, a_ = (t.clone().requires_grad_(True) for t in (normal, light, albedo))
+        d2, t2 = M.get_shading(n_, *M.get_lighting_directions(l_), a_)
+        gt, gd = torch.randn_like(t2), torch.randn_like(d2)
+        gn, gl, ga = torch.autograd.grad((t2 * gt).sum() + (d2 * gd).sum(), (n_, l_, a_))
+        for k_, v in dict(gt=gt, gd=gd, gn=gn, gl=gl, ga=ga).items():
+            out[f"m.shade.{k_}"] = np_(v)
+        # prior pre-training forward (model.py:88-93) incl. its 4-D broadcast
+        x = torch.randn(2, 3, S, S)
+        prior = 0.91 + 0.11 * torch.rand(1, S, S)
+        loss, depth = M.depth_net_forward(x, prior)
+        out["m.dnf.x"], out["m.dnf.prior"] = np_(x), np_(prior)
+        out["m.dnf.loss"], out["m.dnf.depth"] = np_(loss), np_(depth)
+
+        # ---- ViewLightSampler (model.py:448-470): draw order + view_scale, CPU generator
+        with tempfile.TemporaryDirectory() as tmp:
+            vm, lm = torch.randn(6) * 0.1, torch.randn(4) * 0.1
+            a = torch.randn(6, 6) * 0.2
+            vc = a @ a.T + 0.01 * torch.eye(6)
+            b = torch.randn(4, 4) * 0.2
+            lc = b @ b.T + 0.01 * torch.eye(4)
+            torch.save({"mean": vm, "cov": vc}, os.path.join(tmp, "v.pth"))
+            torch.save({"mean": lm, "cov": lc}, os.path.join(tmp, "l.pth"))
+            sampler = ref_model.ViewLightSampler(os.path.join(tmp, "v.pth"), os.path.join(tmp, "l.pth"), 0.5)
+        torch.manual_seed(0)
+        out["vls.views"] = np_(sampler.sample(5, "view"))
+        out["vls.lights"] = np_(sampler.sample(3, "light"))
+        out["vls.views2"] = np_(sampler.sample(2))
+        for k_, v in dict(vm=vm, vc=vc, lm=lm, lc=lc).items():
+            out[f"vls.{k_}"] = np_(v)
+
+    # ---- losses (losses.py:6-79)
+    torch.manual_seed(0)
+    a, b = torch.randn(2, 3, 32, 32), torch.randn(2, 3, 32, 32)
+    mask = (torch.rand(2, 1, 32, 32) > 0.3).float()
+    sigma = torch.rand(2, 1, 32, 32) + 0.1
+    out["l.a"], out["l.b"], out["l.mask"], out["l.sigma"] = np_(a), np_(b), np_(mask), np_(sigma)
+    P, Sm, DL = ref_losses.PhotometricLoss(), ref_losses.SmoothLoss(), ref_losses.DiscriminatorLoss()
+    out["l.photo"] = np_(P(a, b))
+    out["l.photo_mask"] = np_(P(a, b, mask=mask))
+    out["l.photo_sigma"] = np_(P(a, b, mask=mask, conf_sigma=sigma))
+    out["l.smooth3"] = np_(Sm(a[:, 0]))
+    out["l.smooth4"] = np_(Sm(a))
+    out["l.smooth_pyr"] = np_(Sm([a, b[:, :, ::2, ::2]]))
+    ar = a.clone().requires_grad_(True)
+    (g,) = torch.autograd.grad(Sm(ar[:, 0]), ar)
+    out["l.smooth3_grad"] = np_(g)
+    D = mc.FakeD()
+    fake = a.clone().requires_grad_(True)
+    for name, m_ in (("", None), ("_mask", mask)):
+        val = DL(D, fake, b, mask=m_)
+        (g,) = torch.autograd.grad(val, fake)
+        out[f"l.dloss{name}"], out[f"l.dloss{name}_grad"] = np_(val), np_(g)
+    out["l.dloss_ftr2"] = np_(ref_losses.DiscriminatorLoss(ftr_num=2)(D, a, b, mask=mask))
+
+    # ---- priors (priors.py:26-107) from the synthetic parsing mask
+    for size in (64, 128):
+        fm = mc.FakeMaskingModel(size)
+        img = torch.zeros(1, 3, size, size)
+        for name in mc.PRIOR_NAMES:
+            pg = object.__new__(ref_priors.PriorGenerator)   # __init__ loads parsing checkpoints
+            pg.image_size, pg.category, pg.prior = size, "face", name
+            pg.noise_threshold, pg.near, pg.far = 0.7, 0.91, 1.02
+            pg.base_prior = torch.Tensor(1, size, size).fill_(1.02)
+            pg.masking_model = fm
+            if size == 128 and name not in ("ellipsoid", "smoothed_box"):
+                continue
+            out[f"p.{name}.{size}"] = np_(pg(img, device="cpu")).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "model.npz"), **out)
 
 
 def fill_deterministic(module, seed):
@@ -240,12 +390,40 @@ def gan_golden():
     out["d.score"] = np_(score)
     np.savez_compressed(os.path.join(OUT, "gan.npz"), **out)
 
+    # ---- the BASELINE-size generator (configs/face.yml: size 128, z 512, 8 mapping layers,
+    # channel_multiplier 1) at batch 8: image and latent gradient through the reference's own
+    # Generator.forward (stylegan2-pytorch/model.py:545-627).  Weights are NOT stored: the test
+    # refills its state-dict-compatible module with fill_deterministic(seed 77).
+    out = {}
+    g = sg2.Generator(128, 512, 8, channel_multiplier=1)
+    fill_deterministic(g, 77)
+    g.eval()
+    torch.manual_seed(0)
+    w = (0.5 * torch.randn(8, 512)).requires_grad_(True)
+    img, _ = g([w], input_is_w=True, randomize_noise=False)
+    gy = torch.randn(img.shape, generator=torch.Generator().manual_seed(5))  # regenerated by the test
+    (gw,) = torch.autograd.grad(img, w, gy)
+    out["g128.w"], out["g128.img"], out["g128.gw"] = np_(w), np_(img), np_(gw)
+    d = sg2.Discriminator(128, channel_multiplier=1)
+    fill_deterministic(d, 78)
+    d.eval()
+    x = torch.tanh(img.detach()[:2] / img.detach().abs().max() * 3).requires_grad_(True)
+    _, feats = d(x, ftr_num=4)
+    gf = [torch.randn(f.shape, generator=torch.Generator().manual_seed(10 + i)) for i, f in enumerate(feats)]
+    (gx,) = torch.autograd.grad(feats, x, gf)
+    out["d128.gx"] = np_(gx)
+    for i, f in enumerate(feats):   # per-level summaries (the maps themselves are 8 MB): mean, abs-mean, 4x4 pooled
+        out[f"d128.f{i}.pool"] = np_(torch.nn.functional.adaptive_avg_pool2d(f, 4))
+        out[f"d128.f{i}.absmean"] = np_(f.abs().mean((1, 2, 3)))
+    np.savez_compressed(os.path.join(OUT, "gan128.npz"), **out)
+
 
 if __name__ == "__main__":
     ops_golden()
     geometry_golden()
     misc_golden()
     gan_golden()
+    model_golden()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -91,6 +91,7 @@ class _ToyModel(torch.nn.Module):
             setattr(self, f"{name}_net", torch.nn.Linear(12, 4))
         self.batch_mean = None
         self.calls = []
+        self.centres = []   # (step, centre used, this process's own mean)
 
     def _feat(self, images):
         return images.reshape(len(images), -1)[:, :12]
@@ -105,6 +106,7 @@ class _ToyModel(torch.nn.Module):
         a = self.albedo_net(self._feat(images))
         d = self.depth_net(self._feat(images)).detach()
         mean = d.mean() if self.batch_mean is None else self.batch_mean(d)
+        self.centres.append((1, float(mean), float(d.mean())))
         loss = ((a - mean) ** 2).mean()
         z = torch.zeros(len(images), 1)
         return loss, (a, z, z, a, d, None if len(images) == 1 else [None] * len(images))
@@ -117,6 +119,10 @@ class _ToyModel(torch.nn.Module):
 
     def forward_step3(self, image, latent, collected, **kw):
         self.calls.append((3, len(image)))
+        # the inner step-1 pass of step 3 centres the depth (model.py:236,338)
+        d = self.depth_net(self._feat(image)).detach()
+        mean = d.mean() if self.batch_mean is None else self.batch_mean(d)
+        self.centres.append((3, float(mean), float(d.mean())))
         out = sum(getattr(self, f"{n}_net")(self._feat(image)).mean() for n in ("lighting", "viewpoint", "depth", "albedo"))
         return (out - collected[0].mean()) ** 2, None
 
@@ -139,7 +145,7 @@ def _joint_worker(rank, world, port, q, stages):
     t = GeneralizingTrainer2(_ToyModel, dict(_TOY_CFG), device="cpu")
     n = t.fit(_toy_data(), stages=stages, batch_size=2, rank=rank, world_size=world)
     flat = torch.cat([p.detach().reshape(-1) for p in t.model.parameters()])
-    q.put((rank, n, flat.tolist(), list(t.model.calls)))  # plain lists: no shared-memory handles
+    q.put((rank, n, flat.tolist(), list(t.model.calls), list(t.model.centres)))  # plain lists only
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -156,13 +162,13 @@ def _run_joint(world, stages):
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    return [(r, n, torch.tensor(flat), calls) for r, n, flat, calls in res]
+    return [(r, n, torch.tensor(flat), calls, centres) for r, n, flat, calls, centres in res]
 
 
 @pytest.mark.timeout(180)
 def test_joint_trainer_single_process_follows_reference_loop():
     stages = [{"step1": 2, "step2": 1, "step3": 3}]
-    (_, n, _, calls), = _run_joint(1, stages)
+    (_, n, _, calls, _c), = _run_joint(1, stages)
     # 2 epochs x 2 batches of 2 images: step 1 on the batch, then per image step 2 and step 3
     per_batch = [(1, 2)] * 2 + ([(2, 1)] * 1 + [(3, 1)] * 3) * 2
     assert calls == per_batch * 4
@@ -174,11 +180,27 @@ def test_joint_trainer_data_parallel_matches_single_process():
     """Step 1 (batch-mean loss, whole-batch depth mean): two ranks with averaged gradients reproduce
     the single-process run; with steps 2 / 3 the ranks still hold identical parameters."""
     stages = [{"step1": 3, "step2": 0, "step3": 0}]
-    (_, n1, ref, _), = _run_joint(1, stages)
+    (_, n1, ref, _, _c), = _run_joint(1, stages)
     res = _run_joint(2, stages)
     assert [r[1] for r in res] == [n1, n1]
-    for _, _, flat, calls in res:
+    for _, _, flat, calls, _c in res:
         assert all(c == (1, 1) for c in calls)          # each rank sees one image of each batch
         assert float((flat - ref).abs().max()) < 1e-5
     res = _run_joint(2, [{"step1": 1, "step2": 2, "step3": 1}])
     assert torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.timeout(180)
+def test_joint_trainer_depth_centre_scope_under_data_parallelism():
+    """The whole-batch (all ranks) depth centre applies where the reference runs a BATCH of images
+    through the depth net — step 1 (model.py:338) — and not to the per-image step 3, whose inner
+    step-1 pass centres each image by its own mean (trainer.py:452, model.py:236) at any W."""
+    res = _run_joint(2, [{"step1": 1, "step2": 1, "step3": 2}])
+    for _, _, _, _, centres in res:
+        s1 = [(c, own) for k, c, own in centres if k == 1]
+        s3 = [(c, own) for k, c, own in centres if k == 3]
+        assert s1 and s3
+        assert all(c == own for c, own in s3)                 # per-image centre
+        assert any(abs(c - own) > 1e-6 for c, own in s1)      # mean over both ranks' images
+    # both ranks used the SAME centre in step 1
+    assert [c for k, c, _ in res[0][4] if k == 1] == pytest.approx([c for k, c, _ in res[1][4] if k == 1])

@@ -1,0 +1,138 @@
+"""-m gpu: every tile instance of g2s::modconv_kernel (128x128, 128x64, 64x64) and its split-K
+paths on the north-star workload's OWN call signatures, value by value against the C oracle.
+
+The heuristic picks the 128-wide tiles only for M > 64 with >= 512 workgroups and the measured
+table (csrc/modconv_tuned.inc) only for B = 8 / 9 signatures, so small shapes never reach
+modconv_kernel<128,128,18> / <128,64,18> — the instances that carry a third of the benchmarked
+iteration (profiles/r01_c_bench_timed_region.txt).  Here each signature runs with
+    * the built-in choice (tuned table / heuristic),
+    * every tile in {0: 128x128, 1: 128x64, 2: 64x64} x split-K in {1, 4, 7} forced through
+      g2s_modconv_tune,
+forward (in-scale = style, out-scale = demodulation) and transposed (data-gradient: in-scale =
+demodulation), against oracle.capi.modconv (stylegan2-pytorch/model.py:250-291 restated in C,
+double accumulation).  Tolerance: rtol 2e-4, atol 2e-5 * max(1, sqrt(K / 1152)) (fp32 MFMA sums of
+K = Cin * k^2 terms; the summation order is all that differs)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conv_cases import DOWN2, PLAIN, UP2, expected_modconv  # noqa: E402
+
+TILES = (0, 1, 2)
+SPLITS = (1, 4, 7)
+
+
+@pytest.fixture(scope="module")
+def L():
+    import gan2shape_amd  # noqa: F401
+    from gan2shape_amd import lib
+    lib_ = lib.load()
+    assert torch.cuda.is_available()
+    yield lib_
+    lib_.g2s_modconv_tune(-1, -1)
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+
+
+def _check(y, exp, K, what):
+    atol = 2e-5 * max(1.0, math.sqrt(K / 1152.0))
+    got = y.cpu().numpy()
+    assert got.shape == exp.shape, (what, got.shape, exp.shape)
+    np.testing.assert_allclose(got, exp, rtol=2e-4, atol=atol, err_msg=what)
+
+
+# (B, Cin, Cout, H, k, mode): the generator's / discriminator's own layers at B = 8 (SURVEY §8a
+# layer table; D: stylegan2-pytorch/model.py:630-697 at size 128, cm = 1)
+SIGNATURES = [
+    (8, 128, 128, 128, 3, PLAIN),   # G convs[9]: the heaviest <128,128,18> launch
+    (8, 512, 512, 32, 3, PLAIN),    # G convs[5]
+    (8, 512, 256, 32, 3, UP2),      # G convs[6] (transposed stride 2: 4 residue classes)
+    (8, 256, 512, 33, 3, DOWN2),    # D ResBlock conv2 after the blur (stride 2)
+    (8, 128, 256, 129, 3, DOWN2),   # D first ResBlock conv2 (129 = 128 + blur padding)
+    (8, 128, 256, 64, 1, PLAIN),    # D skip 1x1 after the stride-2 blur
+    (8, 512, 512, 16, 3, PLAIN),    # tuned entry: tile 1, split-K 4
+    (8, 512, 512, 17, 3, UP2),      # ragged class sizes (17 -> 35)
+]
+
+
+@pytest.mark.parametrize("transpose", [0, 1])
+@pytest.mark.parametrize("B,cin,cout,H,k,mode", SIGNATURES)
+def test_modconv_every_tile_vs_oracle(L, B, cin, cout, H, k, mode, transpose):
+    from gan2shape_amd.modconv import modconv_raw
+    rng = np.random.default_rng(B * 1000 + cin + cout + H + 7 * mode + transpose)
+    w = (rng.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+    if transpose:
+        # the data-gradient call: x is the gradient w.r.t. the layer output
+        oh = {PLAIN: H, UP2: (H - 1) * 2 + k, DOWN2: (H - k) // 2 + 1}[mode]
+        x = rng.standard_normal((B, cout, oh, oh)).astype(np.float32)
+        s_in = (1 + 0.3 * rng.standard_normal((B, cout))).astype(np.float32)   # demodulation
+        s_out = None
+    else:
+        x = rng.standard_normal((B, cin, H, H)).astype(np.float32)
+        s_in = (1 + 0.3 * rng.standard_normal((B, cin))).astype(np.float32)    # style
+        s_out = (1 + 0.3 * rng.standard_normal((B, cout))).astype(np.float32)  # demodulation
+    exp = expected_modconv(x, w, s_in, s_out, mode, transpose)
+    xd, wd, sid = dev(x), dev(w), dev(s_in)
+    sod = None if s_out is None else dev(s_out)
+    K = (cout if transpose else cin) * k * k
+    try:
+        L.g2s_modconv_tune(-1, -1)
+        _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, "built-in choice")
+        for tile in TILES:
+            for sk in SPLITS:
+                assert L.g2s_modconv_tune(tile, sk) == 0
+                _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, f"tile {tile} split-K {sk}")
+    finally:
+        L.g2s_modconv_tune(-1, -1)
+
+
+# VGG16 trunk of LPIPS at B = 9 (image + 8 projected samples; lpips/pretrained_networks.py:97-135)
+# and the discriminator's ConvLayer: conv + bias + (leaky-)ReLU in one launch, deferred to a second
+# launch when split-K is on.
+@pytest.mark.parametrize("B,cin,cout,H,alpha,gain", [
+    (9, 512, 512, 16, 0.0, 1.0),            # tuned: tile 1, split-K 7 (deferred epilogue)
+    (9, 64, 64, 128, 0.0, 1.0),             # conv1_2: N = 147456 pixels
+    (9, 3, 64, 128, 0.0, 1.0),              # conv1_1: 3 input channels (partial K tile)
+    (8, 128, 128, 128, 0.2, 2 ** 0.5),      # D ResBlock conv1 (FusedLeakyReLU epilogue)
+])
+def test_conv_bias_act_every_tile_vs_oracle(L, B, cin, cout, H, alpha, gain):
+    from gan2shape_amd.modconv import conv_bias_act
+    rng = np.random.default_rng(B + cin + cout + H)
+    x = rng.standard_normal((B, cin, H, H)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    pre = expected_modconv(x, w, None, None, PLAIN, 0) + b[None, :, None, None]
+    exp = (np.where(pre > 0, pre, pre * alpha) * gain).astype(np.float32)
+    # an activation input within the tolerance of zero may take the other slope: compare there
+    # with the absolute tolerance only (|slope difference| * |pre| <= atol)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    try:
+        for tile, sk in [(-1, -1)] + [(t, s) for t in TILES for s in SPLITS]:
+            assert L.g2s_modconv_tune(tile, sk) == 0
+            _check(conv_bias_act(xd, wd, bd, PLAIN, alpha, gain), exp, cin * 9, f"tile {tile} split-K {sk}")
+    finally:
+        L.g2s_modconv_tune(-1, -1)
+
+
+def test_forced_tile_is_honoured_and_restored(L):
+    """g2s_modconv_tune rejects bad arguments and (-1, -1) restores the built-in choice: same bits
+    as before the override for a signature whose built-in choice has no split-K."""
+    from gan2shape_amd.modconv import modconv_raw
+    assert L.g2s_modconv_tune(3, 1) != 0 and L.g2s_modconv_tune(0, 0) != 0
+    torch.manual_seed(0)
+    x = torch.randn(8, 128, 64, 64, device="cuda")
+    w = torch.randn(128, 128, 3, 3, device="cuda") / 34
+    L.g2s_modconv_tune(-1, -1)
+    y0 = modconv_raw(x, w, None, None, PLAIN, 0)
+    L.g2s_modconv_tune(2, 1)
+    y1 = modconv_raw(x, w, None, None, PLAIN, 0)
+    L.g2s_modconv_tune(-1, -1)
+    y2 = modconv_raw(x, w, None, None, PLAIN, 0)
+    assert torch.equal(y0, y2)
+    torch.testing.assert_close(y0, y1, rtol=1e-4, atol=1e-4)

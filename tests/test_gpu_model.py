@@ -522,3 +522,89 @@ def test_other_baseline_configs_run(gan_size, cm, prior, n_proj):
     n = t.fit([(image[0].cpu(), latent[0].cpu(), 0)], stages=[{'step1': 1, 'step2': 1, 'step3': 1}])
     assert n == 3
     assert all(math.isfinite(h[3]) for h in t.history) and len(t.history) == 3
+
+
+def test_graph_capture_on_default_stream_raises():
+    """An eager backward on the legacy default stream followed by a capture ends in a host segfault
+    inside hipStreamEndCapture (gpurun_out/dbg.log of round 1): GraphedSteps.capture refuses to
+    start from the default stream instead."""
+    import bench
+    from gan2shape_amd.graphs import GraphedSteps
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import Trainer
+    dev = torch.device("cuda")
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))
+    torch.manual_seed(0)
+    t = Trainer(GAN2Shape, bench.face_config(n_proj=2), device=dev, capturable=True)
+    image, latent = bench.synthetic_sample(t.model, 1234, dev)
+    g = GraphedSteps(t, image, latent)
+    with pytest.raises(RuntimeError, match="non-default current stream"):
+        g.capture(1)
+    with pytest.raises(RuntimeError, match="non-default current stream"):
+        t.fit([(image[0].cpu(), latent[0].cpu(), 0)], stages=[{'step1': 1, 'step2': 1, 'step3': 1}], graphs=True)
+    with pytest.raises(RuntimeError, match="capturable"):
+        Trainer(GAN2Shape, bench.face_config(n_proj=2), device=dev).fit([], graphs=True)
+
+
+def _fresh_graph_fit_worker(q):
+    import bench
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import Trainer
+    dev = torch.device("cuda")
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    cfg = bench.face_config(n_proj=3)
+    # fewer iterations than the default warm-up in some blocks; two stages, two images
+    stages = [{'step1': 2, 'step2': 1, 'step3': 2}, {'step1': 4, 'step2': 3, 'step3': 1}]
+    out = {}
+    for graphs in (True, False):      # graphs FIRST: nothing has grown any cache before the captures
+        torch.manual_seed(0)
+        t = Trainer(GAN2Shape, cfg, device=dev, capturable=True)
+        data = []
+        for i in range(2):
+            image, latent = bench.synthetic_sample(t.model, 1234 + i, dev)
+            data.append((image[0].cpu(), latent[0].cpu(), i))
+        n = t.fit(data, stages=stages, graphs=graphs)
+        torch.cuda.synchronize()
+        out[graphs] = (n, [(h[0], h[1], h[2], h[3]) for h in t.history])
+    q.put(out)
+
+
+def test_fresh_process_graph_fit_two_stages():
+    """fit(graphs=True) in a process that has run nothing before: step 1 is captured at raster
+    batch 1, step 2 / 3 then run at batch n_proj (the rasterizer scratch is allocated per call, so
+    no captured graph keeps a pointer into a buffer that a later, larger call released).  Iteration
+    counts equal the request even where a block asks for fewer iterations than the warm-up, and the
+    deterministic step-1 blocks agree with the eager loop."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_fresh_graph_fit_worker, args=(q,))
+    p.start()
+    out = q.get(timeout=500)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    (n_g, hist_g), (n_e, hist_e) = out[True], out[False]
+    assert n_g == n_e == 2 * (2 + 1 + 2 + 4 + 3 + 1)
+    assert [h[:3] for h in hist_g] == [h[:3] for h in hist_e] and len(hist_g) == 12
+    assert all(math.isfinite(h[3]) for h in hist_g + hist_e)
+    # image 0, stage 0, step 1: no random draw is involved before it -> same loss in both modes
+    assert abs(hist_g[0][3] - hist_e[0][3]) < 5e-3 * abs(hist_e[0][3])
+
+
+def test_bench_self_launches_ranks():
+    """`python bench.py --gpus 2` without torchrun starts two ranks itself (gloo rehearsal on the one
+    GPU of the test box) and reports n_gpus = 2 with the whole-job rate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["G2S_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
+                        "--warmup", "2", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0
+    assert line["scaling"] == "weak" and line["cpu_baseline"] is None

@@ -150,6 +150,95 @@ def test_priors_from_synthetic_mask():
     assert abs(s.max().item() - 1.02) < 1e-5 and abs(s.min().item() - 0.91) < 1e-5
 
 
+# ----------------------------------------------------------------------------- model-level math (reference fixtures)
+def test_model_math_golden(golden):
+    """rescale / clamp / view / lighting / shading / prior forward of GAN2Shape/model.py:85-93,
+    330-360 — this package's torch path against outputs of the reference's own methods
+    (tests/golden/model.npz)."""
+    from model_cases import bare_model
+    g = golden("model")
+    m = bare_model("cpu")
+    raw = T(g["m.depth_raw"])
+    S = raw.shape[-1]
+    np.testing.assert_allclose(m.rescale_depth(torch.tanh(raw)).numpy(), g["m.rescale"], rtol=1e-6)
+    np.testing.assert_allclose(m.get_clamped_depth(raw, S, S).numpy(), g["m.clamped"], rtol=1e-6)
+    np.testing.assert_allclose(m.get_clamped_depth(raw, S, S, clamp_border=False).numpy(),
+                               g["m.clamped_noborder"], rtol=1e-6)
+    np.testing.assert_allclose(m.get_view_transformation(T(g["m.view"])).numpy(), g["m.view_trans"], rtol=1e-6)
+    la, lb, ld = m.get_lighting_directions(T(g["m.light"]))
+    for got, key in ((la, "m.light_a"), (lb, "m.light_b"), (ld, "m.light_d")):
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-6, atol=1e-7)
+    diffuse, texture = m.get_shading(T(g["m.normal"]), la, lb, ld, T(g["m.albedo"]))
+    np.testing.assert_allclose(diffuse.numpy(), g["m.diffuse"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(texture.numpy(), g["m.texture"], rtol=1e-6, atol=1e-6)
+    a, b, d2, t2 = m._shade(T(g["m.normal"]), T(g["m.light"]), T(g["m.albedo"]))   # the step's entry point
+    np.testing.assert_allclose(t2.numpy(), g["m.texture"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(a.numpy(), g["m.light_a"], rtol=1e-6)
+    loss, depth = m.depth_net_forward(T(g["m.dnf.x"]), T(g["m.dnf.prior"]))
+    assert depth.shape == g["m.dnf.depth"].shape                    # the 4-D (1,B,H,W) broadcast
+    np.testing.assert_allclose(depth.numpy(), g["m.dnf.depth"], rtol=1e-6)
+    np.testing.assert_allclose(loss.item(), g["m.dnf.loss"], rtol=1e-6)
+
+
+def test_view_light_sampler_golden(golden):
+    """ViewLightSampler (model.py:448-470): n sequential MultivariateNormal draws, view_scale on
+    column 1 — a seeded CPU run reproduces the reference's samples exactly."""
+    from gan2shape_amd.model import ViewLightSampler
+    g = golden("model")
+    vls = ViewLightSampler(None, None, 0.5, "cpu",
+                           {"mean": g["vls.vm"].tolist(), "cov": g["vls.vc"].tolist()},
+                           {"mean": g["vls.lm"].tolist(), "cov": g["vls.lc"].tolist()})
+    torch.manual_seed(0)
+    np.testing.assert_allclose(vls.sample(5, "view").numpy(), g["vls.views"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(vls.sample(3, "light").numpy(), g["vls.lights"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(vls.sample(2).numpy(), g["vls.views2"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(vls.view_mean.numpy(), g["vls.vm"])
+
+
+def test_losses_golden(golden):
+    """The three loss classes against outputs of the reference's losses.py:6-79 (fixed fake D from
+    tests/model_cases.py)."""
+    from model_cases import FakeD
+    g = golden("model")
+    a, b, mask, sigma = (T(g[k]) for k in ("l.a", "l.b", "l.mask", "l.sigma"))
+    P, Sm = losses.PhotometricLoss(), losses.SmoothLoss()
+    np.testing.assert_allclose(P(a, b).item(), g["l.photo"], rtol=1e-6)
+    np.testing.assert_allclose(P(a, b, mask=mask).item(), g["l.photo_mask"], rtol=1e-6)
+    np.testing.assert_allclose(P(a, b, mask=mask, conf_sigma=sigma).item(), g["l.photo_sigma"], rtol=1e-6)
+    np.testing.assert_allclose(Sm(a[:, 0]).item(), g["l.smooth3"], rtol=1e-6)
+    np.testing.assert_allclose(Sm(a).item(), g["l.smooth4"], rtol=1e-6)
+    np.testing.assert_allclose(Sm([a, b[:, :, ::2, ::2]]).item(), g["l.smooth_pyr"], rtol=1e-6)
+    ar = a.clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad(Sm(ar[:, 0]), ar)
+    np.testing.assert_allclose(gr.numpy(), g["l.smooth3_grad"], rtol=1e-5, atol=1e-8)
+    D, DL = FakeD(), losses.DiscriminatorLoss()
+    for name, m_ in (("", None), ("_mask", mask)):
+        fake = a.clone().requires_grad_(True)
+        val = DL(D, fake, b, mask=m_)
+        (gr,) = torch.autograd.grad(val, fake)
+        np.testing.assert_allclose(val.item(), g[f"l.dloss{name}"], rtol=1e-6)
+        np.testing.assert_allclose(gr.numpy(), g[f"l.dloss{name}_grad"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(losses.DiscriminatorLoss(ftr_num=2)(D, a, b, mask=mask).item(),
+                               g["l.dloss_ftr2"], rtol=1e-6)
+
+
+def test_priors_golden(golden):
+    """The six priors against the reference's PriorGenerator (priors.py:26-107) fed the same
+    synthetic parsing mask."""
+    from model_cases import PRIOR_NAMES, FakeMaskingModel
+    g = golden("model")
+    for size in (64, 128):
+        fm = FakeMaskingModel(size)
+        img = torch.zeros(1, 3, size, size)
+        for name in PRIOR_NAMES:
+            key = f"p.{name}.{size}"
+            if key not in g:
+                continue
+            source = fm.confidence_mask if "confidence" in name else fm
+            p = priors.PriorGenerator(size, "face", name, masking_model=source)(img, device="cpu")
+            np.testing.assert_allclose(p.numpy(), g[key], rtol=2e-6, atol=1e-6, err_msg=key)
+
+
 # ----------------------------------------------------------------------------- reference (live)
 def _ref_sg2():
     if SG2 not in sys.path:

@@ -124,3 +124,34 @@ def test_group_norm_act_oracle_matches_torch_cpu(shape, groups, slope):
     np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(dg, gt.grad.numpy(), rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("mode,h", [(0, 7), (1, 5), (2, 9)])
+def test_adjoint_weight_identities(mode, h):
+    """tests/conv_cases.py: the data-gradient of each convolution geometry written as a forward
+    call of the oracle with adjoint weights equals torch's autograd of the reference formulation
+    (F.conv2d pad k//2 / F.conv_transpose2d stride 2 / F.conv2d stride 2, model.py:264-289)."""
+    import torch
+    import torch.nn.functional as F
+    from conv_cases import expected_modconv
+    gen = torch.Generator().manual_seed(mode)
+    B, cin, cout, k = 2, 5, 7, 3
+    x = torch.randn(B, cin, h, h, generator=gen, requires_grad=True)
+    w = torch.randn(cout, cin, k, k, generator=gen) / 5
+    s = 1 + 0.3 * torch.randn(B, cin, generator=gen)
+    d = 1 + 0.3 * torch.randn(B, cout, generator=gen)
+    xs = x * s[:, :, None, None]
+    if mode == 0:
+        y = F.conv2d(xs, w, padding=1)
+    elif mode == 1:
+        y = F.conv_transpose2d(xs, w.transpose(0, 1), stride=2)
+    else:
+        y = F.conv2d(xs, w, stride=2)
+    y = y * d[:, :, None, None]
+    fwd = expected_modconv(x.detach().numpy(), w.numpy(), s.numpy(), d.numpy(), mode, 0)
+    np.testing.assert_allclose(fwd, y.detach().numpy(), rtol=1e-5, atol=1e-5)
+    gy = torch.randn(y.shape, generator=gen)
+    (gxs,) = torch.autograd.grad(y, xs, gy)
+    # g2s_modconv(transpose=1): in_scale = demod on the incoming gradient, no output scale
+    bwd = expected_modconv(gy.numpy(), w.numpy(), d.numpy(), None, mode, 1)
+    np.testing.assert_allclose(bwd, gxs.numpy(), rtol=1e-5, atol=1e-5)
