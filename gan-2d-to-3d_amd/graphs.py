@@ -74,7 +74,7 @@ class GraphedSteps:
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 optim.zero_grad(set_to_none=True)
-                self._iteration(kind, src)
+                warm_loss, warm_collected = self._iteration(kind, src)
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
         optim.zero_grad(set_to_none=True)
@@ -83,7 +83,16 @@ class GraphedSteps:
         self.graphs[kind] = g
         self.loss[kind] = loss.detach()
         self.collected[kind] = collected
-        return warmup  # iterations actually executed (a stream capture records, it does not run)
+        # A capture records, it does not run: the graph's static outputs (the loss, the hand-off
+        # to the next step kind) are filled with the results of the last warm-up iteration, so they
+        # are valid even if no replay follows (a block that asks for no more than `warmup`
+        # iterations).
+        with torch.no_grad():
+            self.loss[kind].copy_(warm_loss.detach())
+            for dst, srct in zip(collected or (), warm_collected or ()):
+                if torch.is_tensor(dst):
+                    dst.copy_(srct.detach())
+        return warmup  # iterations actually executed
 
     def run(self, kind):
         """One training iteration of kind `kind` (graph replay)."""
