@@ -22,6 +22,7 @@ SOURCES = {
     "fused_bias_act.hip": [],
     "upfirdn2d.hip": [],
     "modconv.hip": [],
+    "winograd.hip": [],
     "rowops.hip": [],
     "lpips.hip": [],
     "geometry.hip": ["-ffp-contract=off"],

@@ -1,0 +1,397 @@
+// winograd.hip — 3x3 stride-1 convolution (padding 1) as Winograd F(2x2, 3x3) on the fp32 matrix
+// cores of gfx950.
+//
+// Serves the stride-1 3x3 layers of the FROZEN networks of a GAN2Shape step — the generator's plain
+// StyledConvs (stylegan2-pytorch/model.py:285-289), the discriminator's ResBlock conv1
+// (model.py:679-697), the whole VGG16 trunk of LPIPS (lpips/pretrained_networks.py:97-135) — and
+// their data-gradients: two thirds of the step's convolution FLOP.  Same contract as g2s_modconv
+// (input scale = style, output scale = demodulation, optional bias + leaky-ReLU epilogue), results
+// equal up to fp32 rounding (exact-arithmetic identity; transform constants are 0, +-1, +-1/2).
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        per 2x2 output tile, 4x4 input patch d
+//
+// i.e. 16 independent GEMMs  M_p[Cout][tiles] = U_p[Cout][Cin] V_p[Cin][tiles]  (p = 4i + j): 16
+// multiplications per 4 outputs instead of 36 — 2.25x fewer MFMA operations than the direct
+// implicit GEMM.
+//
+//   * U = G g G^T is computed ONCE per weight tensor (g2s_wino_weights; the weights of G / D / VGG
+//     are constants of the training step) into a tiled layout [m-tile][k-tile][p][4 ch][64 m], so a
+//     K tile of one m-tile is one contiguous 16 KB block: staged with 16-byte loads / LDS writes.
+//   * V = B^T d B is never materialised in memory: each thread gathers the 4x4 patch of one
+//     (tile, channel) from global memory (buffer loads with loop-invariant offsets; the hardware
+//     range check supplies the zero padding), applies the style scale, transforms in registers and
+//     writes the 16 values to the 16 LDS planes.
+//   * Workgroup = 64 output channels x 64 tiles (256 output pixels), 4 waves (2 x 2), each wave owns
+//     a 32 x 32 block of ALL 16 positions: 16 accumulators of v_mfma_f32_32x32x2_f32 = 256
+//     registers per lane, one wave per SIMD.  The output transform A^T M A then happens entirely in
+//     registers (the 16 positions of one (channel, tile) live in one lane) and feeds the
+//     demodulation / bias / activation epilogue; outputs leave as float2 rows.
+//   * K tile = 4 channels = 32 MFMAs per wave (2048 matrix-pipe cycles); the staging of tile t+1
+//     and the loads of tile t+2 are issued between those MFMAs; LDS double-buffered, one barrier
+//     per K tile.
+#include <algorithm>
+#include "g2s_common.h"
+#include "xcd_tile.h"
+
+namespace g2s {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WBM = 64;       // output channels per workgroup
+constexpr int WBT = 64;       // 2x2 output tiles per workgroup
+constexpr int WKC = 4;        // channels per K tile
+constexpr int WTHREADS = 256;
+constexpr int WBLOCK = 16 * WKC * WBM;  // floats of one (m-tile, k-tile) block of U
+
+struct WinoDesc {
+    const float *x, *U, *in_scale, *out_scale, *bias;
+    float *y;
+    int B, Cr, M, H, W;
+    int TH, TW;          // tiles per image (ceil(H/2), ceil(W/2))
+    int ktiles, splitk;
+    int act;
+    float act_alpha, act_gain;
+};
+
+// PARTIAL: Cr is not a multiple of the K tile (the last tile's surplus channels read as zero).
+// FAST: the 64 tiles of a workgroup are whole tile rows of one image (64 % TW == 0, W even): a lane
+// then loads only the two MIDDLE columns of its 4x4 patch (one aligned 8-byte load per patch row,
+// the wave reads 512 contiguous bytes) and takes the outer columns from its neighbour lanes — 4
+// fully coalesced loads per K tile instead of 16 strided ones (the vector L1 is the busiest unit of
+// this kernel: the matrix work per loaded byte is 2.25x smaller than in the direct GEMM).
+template <bool SCALE, bool PARTIAL, bool FAST>
+__global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
+    __shared__ __attribute__((aligned(16))) float Us[2][16 * WKC * WBM];
+    __shared__ __attribute__((aligned(16))) float Vs[2][16 * WKC * WBT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lk = lane >> 5;
+    const int tiles_m = (d.M + WBM - 1) / WBM;
+    const int tile_id = xcd_logical_tile();
+    const int mt = tile_id % tiles_m, nt = tile_id / tiles_m;
+    const int per_img = d.TH * d.TW, Ntiles = d.B * per_img;
+    if (nt * WBT >= Ntiles) return;
+    const int per = (d.ktiles + d.splitk - 1) / d.splitk;
+    const int kt_begin = blockIdx.y * per, kt_end = min(d.ktiles, kt_begin + per);
+    if (kt_begin >= kt_end) return;
+    const int HW = d.H * d.W;
+    constexpr int OOB = 0x7fffffff;
+
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, d.B * d.Cr * HW * 4, 0x00020000);
+    const auto ru = __builtin_amdgcn_make_buffer_rsrc((void *)d.U, 0, tiles_m * d.ktiles * WBLOCK * 4, 0x00020000);
+    const auto rsc = __builtin_amdgcn_make_buffer_rsrc((void *)(SCALE ? d.in_scale : d.x), 0,
+                                                       SCALE ? d.B * d.Cr * 4 : 4, 0x00020000);
+
+    // ---- input patch of this thread: tile t = lane of the block, channel kc = wave of the K tile
+    const int kc = wave;
+    constexpr int ND = FAST ? 4 : 16;   // loads per patch
+    int offD[ND];
+    int offS = OOB;
+    bool first_col = false, last_col = false;
+    {
+        const int n = nt * WBT + lane;
+        const bool valid = n < Ntiles;
+        const int b = valid ? n / per_img : 0, r = valid ? n % per_img : 0;
+        const int ty = r / d.TW, tx = r % d.TW;
+        const int base = (b * d.Cr + kc) * HW;
+        first_col = tx == 0;
+        last_col = tx == d.TW - 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int iy = 2 * ty - 1 + i;
+            const bool row_ok = valid & (iy >= 0) & (iy < d.H);
+            if constexpr (FAST) {
+                offD[i] = row_ok ? (base + iy * d.W + 2 * tx) * 4 : OOB;   // columns 2tx, 2tx+1
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int ix = 2 * tx - 1 + j;
+                    offD[i * 4 + j] = (row_ok & (ix >= 0) & (ix < d.W)) ? (base + iy * d.W + ix) * 4 : OOB;
+                }
+            }
+        }
+        if (valid) offS = (b * d.Cr + kc) * 4;
+    }
+    const int offU = tid * 16;  // bytes: float4 number tid (+ 256 per e) of the 16 KB block
+
+    float rd[16], rs = 1.0f;    // FAST: rd[i*4+1], rd[i*4+2] hold the loaded middle columns
+    f32x4 ru4[4];
+    auto load_tile = [&](int kt) {
+        // surplus channels of the last tile: an out-of-range offset makes the hardware return 0
+        const int kill = (PARTIAL && kt * WKC + kc >= d.Cr) ? OOB : 0;  // wave-uniform
+        const int so = kt * WKC * HW * 4;
+        if constexpr (FAST) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rx, offD[i] | kill, so, 0);
+                rd[i * 4 + 1] = __uint_as_float(v.x);
+                rd[i * 4 + 2] = __uint_as_float(v.y);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                rd[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, offD[e] | kill, so, 0));
+        }
+        if constexpr (SCALE)
+            rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, offS | kill, kt * WKC * 4, 0));
+        const int su = (mt * d.ktiles + kt) * WBLOCK * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ru, offU + e * 4096, su, 0);
+            ru4[e] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        }
+    };
+    // B^T d B of the registers -> the 16 planes of buffer `buf`; U block -> buffer `buf`
+    auto stage_tile = [&](int buf) {
+        float t[16];
+        if constexpr (FAST) {
+            // outer columns from the neighbour tiles of the same tile row (zero at the image border)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float left = __shfl_up(rd[i * 4 + 2], 1, 64), right = __shfl_down(rd[i * 4 + 1], 1, 64);
+                rd[i * 4 + 0] = first_col ? 0.0f : left;
+                rd[i * 4 + 3] = last_col ? 0.0f : right;
+            }
+        }
+        if constexpr (SCALE) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) rd[e] *= rs;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            t[0 * 4 + j] = rd[0 * 4 + j] - rd[2 * 4 + j];
+            t[1 * 4 + j] = rd[1 * 4 + j] + rd[2 * 4 + j];
+            t[2 * 4 + j] = rd[2 * 4 + j] - rd[1 * 4 + j];
+            t[3 * 4 + j] = rd[1 * 4 + j] - rd[3 * 4 + j];
+        }
+        float *vb = &Vs[0][kc * WBT + lane] + buf * (16 * WKC * WBT);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            vb[(i * 4 + 0) * WKC * WBT] = t[i * 4 + 0] - t[i * 4 + 2];
+            vb[(i * 4 + 1) * WKC * WBT] = t[i * 4 + 1] + t[i * 4 + 2];
+            vb[(i * 4 + 2) * WKC * WBT] = t[i * 4 + 2] - t[i * 4 + 1];
+            vb[(i * 4 + 3) * WKC * WBT] = t[i * 4 + 1] - t[i * 4 + 3];
+        }
+        f32x4 *ub = reinterpret_cast<f32x4 *>(&Us[0][0] + buf * (16 * WKC * WBM)) + tid;
+#pragma unroll
+        for (int e = 0; e < 4; e++) ub[e * 256] = ru4[e];
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; p++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[p][r] = 0.0f;
+
+    const int kt_last = kt_end - 1;
+    const int aoff = lk * WBM + wm * 32 + l31;   // + (p * WKC + 2 ks) * WBM
+    const int boff = lk * WBT + wn * 32 + l31;
+    // operand fragments of one k-step (2 channels) of all 16 positions
+    float fa0[16], fb0[16], fa1[16], fb1[16];
+    auto read_frags = [&](int buf, const int ks, float (&fa)[16], float (&fb)[16]) {
+        const float *ua = &Us[0][aoff] + buf * (16 * WKC * WBM);
+        const float *vb = &Vs[0][boff] + buf * (16 * WKC * WBT);
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+            fa[p] = ua[(p * WKC + 2 * ks) * WBM];
+            fb[p] = vb[(p * WKC + 2 * ks) * WBT];
+        }
+    };
+
+    load_tile(kt_begin);
+    stage_tile(0);
+    load_tile(min(kt_begin + 1, kt_last));
+    __syncthreads();
+    read_frags(0, 0, fa0, fb0);
+
+    // Software pipeline of one K tile (ONE loop body: the 256 accumulator registers must not be
+    // shuffled between copies of the body):
+    //   phase 1  MFMAs of k-step 0 (fragments read at the end of the previous iteration), while the
+    //            fragments of k-step 1 are read, tile kt+1 (in registers since the previous
+    //            iteration: a full MFMA phase of latency budget) is transformed and written to the
+    //            free buffer, and the registers are re-loaded with tile kt+2;
+    //   phase 2  12 MFMAs of k-step 1; LDS hand-over (raw barrier: a __syncthreads() would drain the
+    //            global loads just issued); read the k-step-0 fragments of tile kt+1 under the last
+    //            4 MFMAs of k-step 1, so that the matrix pipe does not wait for LDS after the barrier.
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; kt++, cur ^= 1) {
+        read_frags(cur, 1, fa1, fb1);
+        stage_tile(cur ^ 1);
+        load_tile(min(kt + 2, kt_last));
+#pragma unroll
+        for (int p = 0; p < 16; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[p], fb0[p], acc[p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 12; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p], fb1[p], acc[p], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        read_frags(cur ^ 1, 0, fa0, fb0);
+#pragma unroll
+        for (int p = 12; p < 16; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p], fb1[p], acc[p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: output transform A^T M A in registers, scale / bias / activation, store.
+    // C layout of the 32x32 MFMA: row m = (r & 3) + 8 (r >> 2) + 4 lk, column n = l31.
+    const int n = nt * WBT + wn * 32 + l31;
+    if (n >= Ntiles) return;
+    const int b = n / per_img, rr = n % per_img;
+    const int oy = 2 * (rr / d.TW), ox = 2 * (rr % d.TW);
+    const bool row1 = oy + 1 < d.H, col1 = ox + 1 < d.W;
+    const bool vec = col1 && (d.W & 1) == 0 && d.splitk == 1;
+    float *yb = d.y + ((size_t)b * d.M * d.H + oy) * d.W + ox;
+    const float *ob = d.out_scale ? d.out_scale + (size_t)b * d.M : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int m = mt * WBM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= d.M) continue;
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            s0[j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+            s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+        }
+        float y[4] = {s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
+        const float sc = ob ? ob[m] : 1.0f;
+        const float bi = d.bias ? d.bias[m] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float v = y[q] * sc + bi;
+            if (d.act) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
+            y[q] = v;
+        }
+        float *dst = yb + (size_t)m * HW;
+        if (vec) {
+            *reinterpret_cast<float2 *>(dst) = float2{y[0], y[1]};
+            if (row1) *reinterpret_cast<float2 *>(dst + d.W) = float2{y[2], y[3]};
+        } else if (d.splitk > 1) {
+            unsafeAtomicAdd(dst, y[0]);
+            if (col1) unsafeAtomicAdd(dst + 1, y[1]);
+            if (row1) unsafeAtomicAdd(dst + d.W, y[2]);
+            if (row1 && col1) unsafeAtomicAdd(dst + d.W + 1, y[3]);
+        } else {
+            dst[0] = y[0];
+            if (col1) dst[1] = y[1];
+            if (row1) dst[d.W] = y[2];
+            if (row1 && col1) dst[d.W + 1] = y[3];
+        }
+    }
+}
+
+// U = G g G^T of every (output channel m, reduction channel c) into the tiled layout.
+// w(m, c, ky, kx) = w[m * w_ms + c * w_ks + (flip ? 8 - (3 ky + kx) : 3 ky + kx)].
+__global__ void wino_weights_kernel(const float *w, float *U, int M, int Cr, int w_ms, int w_ks, int flip,
+                                    int ktiles) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * Cr) return;
+    const int m = idx % M, c = idx / M;
+    float g[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) g[t] = w[(size_t)m * w_ms + (size_t)c * w_ks + (flip ? 8 - t : t)];
+    // rows: G g  (4 x 3)
+    float h[12];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        h[0 * 3 + j] = g[0 * 3 + j];
+        h[1 * 3 + j] = 0.5f * (g[0 * 3 + j] + g[1 * 3 + j] + g[2 * 3 + j]);
+        h[2 * 3 + j] = 0.5f * (g[0 * 3 + j] - g[1 * 3 + j] + g[2 * 3 + j]);
+        h[3 * 3 + j] = g[2 * 3 + j];
+    }
+    float *dst = U + ((size_t)((m / WBM) * ktiles + c / WKC) * 16 * WKC + (c % WKC)) * WBM + (m % WBM);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float u0 = h[i * 3 + 0];
+        const float u1 = 0.5f * (h[i * 3 + 0] + h[i * 3 + 1] + h[i * 3 + 2]);
+        const float u2 = 0.5f * (h[i * 3 + 0] - h[i * 3 + 1] + h[i * 3 + 2]);
+        const float u3 = h[i * 3 + 2];
+        dst[(size_t)(i * 4 + 0) * WKC * WBM] = u0;
+        dst[(size_t)(i * 4 + 1) * WKC * WBM] = u1;
+        dst[(size_t)(i * 4 + 2) * WKC * WBM] = u2;
+        dst[(size_t)(i * 4 + 3) * WKC * WBM] = u3;
+    }
+}
+
+}  // namespace g2s
+
+using namespace g2s;
+
+extern "C" size_t g2s_wino_weights_floats(int M, int Cr) {
+    if (M <= 0 || Cr <= 0) return 0;
+    return (size_t)cdiv(M, WBM) * cdiv(Cr, WKC) * WBLOCK;
+}
+
+extern "C" int g2s_wino_weights(const float *w, float *U, int Cout, int Cin, int transpose, g2s_stream_t stream) {
+    G2S_REQUIRE(w && U, "w, U must not be NULL");
+    G2S_REQUIRE(Cout > 0 && Cin > 0, "sizes must be positive");
+    // forward: M = Cout, reduction over Cin, taps as stored.  transpose (data-gradient): M = Cin,
+    // reduction over Cout, taps flipped: w'(i, o, ky, kx) = w(o, i, 2 - ky, 2 - kx).
+    const int M = transpose ? Cin : Cout, Cr = transpose ? Cout : Cin;
+    const int w_ms = transpose ? 9 : Cin * 9, w_ks = transpose ? Cin * 9 : 9;
+    hipStream_t st = as_stream(stream);
+    const size_t n = g2s_wino_weights_floats(M, Cr);
+    if (hipMemsetAsync(U, 0, n * sizeof(float), st) != hipSuccess) return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(U) failed");
+    wino_weights_kernel<<<cdiv((long)M * Cr, 256), 256, 0, st>>>(w, U, M, Cr, w_ms, w_ks, transpose ? 1 : 0, cdiv(Cr, WKC));
+    return check_launch("g2s_wino_weights");
+}
+
+extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_scale, const float *out_scale,
+                                const float *bias, float *y, int B, int Cr, int M, int H, int W, int act,
+                                float alpha, float gain, int splitk, g2s_stream_t stream) {
+    G2S_REQUIRE(x && U && y, "x, U, y must not be NULL");
+    G2S_REQUIRE(B > 0 && Cr > 0 && M > 0 && H >= 2 && W >= 2, "sizes must be positive (H, W >= 2)");
+    G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
+    G2S_REQUIRE((long)B * Cr * H * W < (1l << 29) && (long)B * M * H * W < (1l << 29) &&
+                    g2s_wino_weights_floats(M, Cr) < ((size_t)1 << 29),
+                "problem too large for 32-bit byte offsets");
+    WinoDesc d{};
+    d.x = x;
+    d.U = U;
+    d.in_scale = in_scale;
+    d.out_scale = out_scale;
+    d.bias = bias;
+    d.y = y;
+    d.B = B;
+    d.Cr = Cr;
+    d.M = M;
+    d.H = H;
+    d.W = W;
+    d.TH = (H + 1) / 2;
+    d.TW = (W + 1) / 2;
+    d.ktiles = cdiv(Cr, WKC);
+    d.act = act;
+    d.act_alpha = alpha;
+    d.act_gain = gain;
+    const int tiles = cdiv(M, WBM) * cdiv((long)B * d.TH * d.TW, WBT);
+    if (splitk <= 0) {  // fill the 256 CUs (one workgroup per CU: 512 registers per lane)
+        splitk = 1;
+        while (tiles * splitk < 256 && d.ktiles / (splitk * 2) >= 8 && splitk < 32) splitk *= 2;
+    }
+    splitk = std::max(1, std::min(splitk, d.ktiles));
+    const bool deferred = splitk > 1 && (bias != nullptr || act != 0);
+    if (deferred) {
+        d.bias = nullptr;
+        d.act = 0;
+    }
+    d.splitk = splitk;
+    hipStream_t st = as_stream(stream);
+    if (splitk > 1 && hipMemsetAsync(y, 0, (size_t)B * M * H * W * sizeof(float), st) != hipSuccess)
+        return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
+    dim3 grid(tiles, splitk, 1);
+    const bool partial = Cr % WKC != 0;
+    // whole tile rows per workgroup and 8-byte aligned row pairs: see FAST above
+    const bool fast = d.TW <= WBT && WBT % d.TW == 0 && W % 2 == 0;
+#define G2S_WINO_LAUNCH(S_, P_, F_) wino_kernel<S_, P_, F_><<<grid, WTHREADS, 0, st>>>(d)
+    if (in_scale) {
+        if (partial) { if (fast) G2S_WINO_LAUNCH(true, true, true); else G2S_WINO_LAUNCH(true, true, false); }
+        else { if (fast) G2S_WINO_LAUNCH(true, false, true); else G2S_WINO_LAUNCH(true, false, false); }
+    } else {
+        if (partial) { if (fast) G2S_WINO_LAUNCH(false, true, true); else G2S_WINO_LAUNCH(false, true, false); }
+        else { if (fast) G2S_WINO_LAUNCH(false, false, true); else G2S_WINO_LAUNCH(false, false, false); }
+    }
+#undef G2S_WINO_LAUNCH
+    int rc = check_launch("g2s_conv3x3_wino");
+    if (rc != G2S_OK || !deferred) return rc;
+    return g2s_fused_bias_act(y, bias, nullptr, y, (int64_t)B * M * H * W, (int64_t)H * W, M, act ? 3 : 1, 0,
+                              alpha, act ? gain : 1.0f, G2S_F32, stream);
+}

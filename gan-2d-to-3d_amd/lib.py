@@ -28,6 +28,9 @@ SIGNATURES = {
     "g2s_modconv": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "g2s_conv_bias_act": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
     "g2s_modconv_tune": (_i, [_i, _i]),
+    "g2s_wino_weights_floats": (_sz, [_i, _i]),
+    "g2s_wino_weights": (_i, [_p, _p, _i, _i, _i, _p]),
+    "g2s_conv3x3_wino": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "g2s_conv2d": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_i, _f, _f, _i, _p]),
     "g2s_conv2d_wgrad": (_i, [_p, _p, _p] + [_i] * 10 + [_i, _p]),
     "g2s_rows_dot_scale": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),

@@ -26,11 +26,14 @@ PROFILE = None
 
 
 class profiled:
-    """with profiled(flop, nbytes): <one launch of g2s::modconv_kernel>"""
+    """with profiled(flop, nbytes[, mfma_flop]): <one launch of the MFMA convolution kernels>.
+    `flop` is the ALGORITHMIC count of the direct convolution; `mfma_flop` what the matrix cores
+    execute (smaller for the Winograd kernel: 16 multiplications per 4 outputs instead of 36)."""
 
-    def __init__(self, flop, nbytes):
+    def __init__(self, flop, nbytes, mfma_flop=None):
         self.rec = PROFILE
         self.flop, self.nbytes = flop, nbytes
+        self.mfma_flop = flop if mfma_flop is None else mfma_flop
 
     def __enter__(self):
         if self.rec is not None:
@@ -41,7 +44,7 @@ class profiled:
     def __exit__(self, *exc):
         if self.rec is not None:
             self.e1.record()
-            self.rec.append((self.flop, self.e0, self.e1, self.nbytes))
+            self.rec.append((self.flop, self.e0, self.e1, self.nbytes, self.mfma_flop))
         return False
 
 
@@ -51,6 +54,51 @@ def out_size(h, k, mode):
     if mode == UP2:
         return (h - 1) * 2 + k
     return (h - k) // 2 + 1
+
+
+# Winograd F(2x2, 3x3) for the stride-1 3x3 layers (csrc/winograd.hip).  WINOGRAD = False forces the
+# direct implicit GEMM everywhere; layers with fewer than WINO_MIN_TILES 2x2 output tiles (too few
+# workgroups for the 64-channel x 64-tile blocks) stay on the direct kernel.
+WINOGRAD = True
+WINO_MIN_TILES = 512
+WINO_SPLITK = 0   # 0: chosen by the library; tests / tuning tools force a value
+_WINO_U = {}  # (data_ptr, version, shape, transpose) -> (w, U): transformed weights of constant tensors
+
+
+def wino_eligible(x, w, mode, H, W):
+    return (WINOGRAD and mode == PLAIN and w.shape[2] == 3 and w.shape[3] == 3 and not w.requires_grad
+            and H >= 2 and W >= 2 and x.shape[0] * ((H + 1) // 2) * ((W + 1) // 2) >= WINO_MIN_TILES)
+
+
+def wino_weights(w, transpose):
+    """U = G g G^T of a constant weight tensor [Cout, Cin, 3, 3] in the library's tiled layout,
+    computed once per (tensor, version, direction)."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), int(transpose))
+    hit = _WINO_U.get(key)
+    if hit is None:
+        if len(_WINO_U) > 256:
+            _WINO_U.clear()
+        Cout, Cin = w.shape[:2]
+        L = _lib.load()
+        M, Cr = (Cin, Cout) if transpose else (Cout, Cin)
+        U = torch.empty(L.g2s_wino_weights_floats(M, Cr), dtype=torch.float32, device=w.device)
+        _lib.check(L.g2s_wino_weights(_lib.ptr(w), _lib.ptr(U), Cout, Cin, int(transpose), _lib.stream()))
+        hit = _WINO_U[key] = (w, U)   # holds `w`: its data_ptr stays unique while cached
+    return hit[1]
+
+
+def _wino_launch(x, w, in_scale, out_scale, bias, transpose, act, alpha, gain, y):
+    B, Cr, H, W = x.shape
+    M = y.shape[1]
+    U = wino_weights(w, transpose)
+    L = _lib.load()
+    tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+    with profiled(2.0 * B * M * Cr * 9 * H * W, 4.0 * (x.numel() + w.numel() + y.numel()),
+                  2.0 * 16 * tiles * M * Cr):
+        _lib.check(L.g2s_conv3x3_wino(_lib.ptr(x), _lib.ptr(U), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                      _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W, int(act), float(alpha),
+                                      float(gain), int(WINO_SPLITK), _lib.stream()))
+    return y
 
 
 def modconv_raw(x, w, in_scale, out_scale, mode, transpose):
@@ -78,6 +126,8 @@ def modconv_raw(x, w, in_scale, out_scale, mode, transpose):
     y = torch.empty((B, cy, oh, ow), dtype=torch.float32, device=x.device)
     si = None if in_scale is None else in_scale.contiguous()
     so = None if out_scale is None else out_scale.contiguous()
+    if wino_eligible(x, w, mode, H, W):
+        return _wino_launch(x, w, si, so, None, transpose, 0, 0.0, 1.0, y)
     L = _lib.load()
     # algorithmic FLOP: 2 * B * Cout * Cin * k^2 * (spatial positions of the un-strided side);
     # algorithmic bytes: each operand once
@@ -248,10 +298,13 @@ class ConvBiasActFunction(Function):
         Cout, _, k, _ = w.shape
         oh, ow = out_size(H, k, mode), out_size(W, k, mode)
         y = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device)
-        L = _lib.load()
-        with profiled(2.0 * B * Cout * Cin * k * k * oh * ow, 4.0 * (x.numel() + w.numel() + y.numel())):
-            _lib.check(L.g2s_conv_bias_act(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cin,
-                                           Cout, H, W, k, mode, 1, float(alpha), float(gain), _lib.stream()))
+        if wino_eligible(x, w, mode, H, W):
+            _wino_launch(x, w, None, None, bias, 0, 1, alpha, gain, y)
+        else:
+            L = _lib.load()
+            with profiled(2.0 * B * Cout * Cin * k * k * oh * ow, 4.0 * (x.numel() + w.numel() + y.numel())):
+                _lib.check(L.g2s_conv_bias_act(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cin,
+                                               Cout, H, W, k, mode, 1, float(alpha), float(gain), _lib.stream()))
         ctx.save_for_backward(w, y)
         ctx.cfg = (mode, float(alpha), float(gain))
         return y

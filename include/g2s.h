@@ -180,6 +180,28 @@ int g2s_conv2d(const float *x, const float *w, const float *bias, float *y, int 
 int g2s_conv2d_wgrad(const float *A, const float *G, float *dw, int B, int Ca, int Cg, int PH, int PW,
                      int GH, int GW, int k, int stride, int pad, int dw_is_zero, g2s_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 3x3 stride-1 convolution (padding 1) as Winograd F(2x2, 3x3) on the fp32 matrix cores
+ * (csrc/winograd.hip): the same map as g2s_modconv(mode = G2S_CONV_PLAIN, k = 3) — the generator's
+ * plain StyledConvs (stylegan2-pytorch/model.py:285-289), the discriminator's ResBlock conv1
+ * (model.py:679-697), the VGG16 trunk of LPIPS (lpips/pretrained_networks.py:97-135) and their
+ * data-gradients — with 2.25x fewer multiplications; results equal up to fp32 rounding.
+ *
+ * g2s_wino_weights: U = G g G^T for every (output, reduction) channel pair of w [Cout, Cin, 3, 3],
+ *   written to U (g2s_wino_weights_floats(M, Cr) floats, tiled layout private to the library).
+ *   transpose = 0: M = Cout, Cr = Cin (forward).  transpose = 1: M = Cin, Cr = Cout, taps flipped
+ *   (the data-gradient of the forward map).  Done once per weight tensor by the caller.
+ * g2s_conv3x3_wino: y[b,m] = act(out_scale[b,m] * sum_c conv3x3(in_scale[b,c] * x[b,c], w(m,c)) + bias[m])
+ *   x [B, Cr, H, W], y [B, M, H, W]; in_scale [B, Cr], out_scale [B, M], bias [M] may be NULL;
+ *   act 0: none, 1: leaky-ReLU(alpha) * gain.  splitk = 0: chosen by the library (partial sums by
+ *   float atomics into a cleared y, epilogue deferred to one elementwise launch).
+ * ---------------------------------------------------------------------------------------- */
+size_t g2s_wino_weights_floats(int M, int Cr);
+int g2s_wino_weights(const float *w, float *U, int Cout, int Cin, int transpose, g2s_stream_t stream);
+int g2s_conv3x3_wino(const float *x, const float *U, const float *in_scale, const float *out_scale,
+                     const float *bias, float *y, int B, int Cr, int M, int H, int W, int act,
+                     float alpha, float gain, int splitk, g2s_stream_t stream);
+
 /* Tuning hook (tools/tune_modconv.py): force the tile configuration (0: 128x128, 1: 128x64,
  * 2: 64x64 output channels x pixels) and/or the split-K factor of the calling thread's following
  * g2s_modconv / g2s_conv_bias_act launches; -1 restores the built-in choice (measured table

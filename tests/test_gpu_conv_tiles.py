@@ -36,6 +36,18 @@ def L():
     lib_.g2s_modconv_tune(-1, -1)
 
 
+class direct_kernel:
+    """Route the stride-1 3x3 layers to the direct implicit GEMM (they default to Winograd)."""
+
+    def __enter__(self):
+        from gan2shape_amd import modconv
+        self.mc, self.saved = modconv, modconv.WINOGRAD
+        modconv.WINOGRAD = False
+
+    def __exit__(self, *exc):
+        self.mc.WINOGRAD = self.saved
+
+
 def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
 
@@ -83,11 +95,13 @@ def test_modconv_every_tile_vs_oracle(L, B, cin, cout, H, k, mode, transpose):
     K = (cout if transpose else cin) * k * k
     try:
         L.g2s_modconv_tune(-1, -1)
-        _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, "built-in choice")
-        for tile in TILES:
-            for sk in SPLITS:
-                assert L.g2s_modconv_tune(tile, sk) == 0
-                _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, f"tile {tile} split-K {sk}")
+        _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, "built-in choice (Winograd where eligible)")
+        with direct_kernel():
+            _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, "built-in direct choice")
+            for tile in TILES:
+                for sk in SPLITS:
+                    assert L.g2s_modconv_tune(tile, sk) == 0
+                    _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, f"tile {tile} split-K {sk}")
     finally:
         L.g2s_modconv_tune(-1, -1)
 
@@ -113,9 +127,11 @@ def test_conv_bias_act_every_tile_vs_oracle(L, B, cin, cout, H, alpha, gain):
     # with the absolute tolerance only (|slope difference| * |pre| <= atol)
     xd, wd, bd = dev(x), dev(w), dev(b)
     try:
-        for tile, sk in [(-1, -1)] + [(t, s) for t in TILES for s in SPLITS]:
-            assert L.g2s_modconv_tune(tile, sk) == 0
-            _check(conv_bias_act(xd, wd, bd, PLAIN, alpha, gain), exp, cin * 9, f"tile {tile} split-K {sk}")
+        _check(conv_bias_act(xd, wd, bd, PLAIN, alpha, gain), exp, cin * 9, "built-in choice (Winograd)")
+        with direct_kernel():
+            for tile, sk in [(-1, -1)] + [(t, s) for t in TILES for s in SPLITS]:
+                assert L.g2s_modconv_tune(tile, sk) == 0
+                _check(conv_bias_act(xd, wd, bd, PLAIN, alpha, gain), exp, cin * 9, f"tile {tile} split-K {sk}")
     finally:
         L.g2s_modconv_tune(-1, -1)
 
@@ -128,11 +144,75 @@ def test_forced_tile_is_honoured_and_restored(L):
     torch.manual_seed(0)
     x = torch.randn(8, 128, 64, 64, device="cuda")
     w = torch.randn(128, 128, 3, 3, device="cuda") / 34
-    L.g2s_modconv_tune(-1, -1)
-    y0 = modconv_raw(x, w, None, None, PLAIN, 0)
-    L.g2s_modconv_tune(2, 1)
-    y1 = modconv_raw(x, w, None, None, PLAIN, 0)
-    L.g2s_modconv_tune(-1, -1)
-    y2 = modconv_raw(x, w, None, None, PLAIN, 0)
+    with direct_kernel():
+        L.g2s_modconv_tune(-1, -1)
+        y0 = modconv_raw(x, w, None, None, PLAIN, 0)
+        L.g2s_modconv_tune(2, 1)
+        y1 = modconv_raw(x, w, None, None, PLAIN, 0)
+        L.g2s_modconv_tune(-1, -1)
+        y2 = modconv_raw(x, w, None, None, PLAIN, 0)
     assert torch.equal(y0, y2)
     torch.testing.assert_close(y0, y1, rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- Winograd F(2x2, 3x3)
+WINO_CASES = [  # B, Cin, Cout, H, W
+    (8, 128, 128, 128, 128),   # G convs[9]
+    (8, 512, 512, 32, 32),     # G convs[5]
+    (8, 512, 512, 16, 16),     # G convs[3]: 512 tiles, split-K by the library
+    (9, 256, 512, 16, 16),     # VGG conv4_1 at B = 9
+    (2, 64, 64, 128, 128),     # VGG conv1_2 of step 1 (B = 2)
+    (2, 3, 64, 64, 64),        # 3 input channels: partial K tile
+    (3, 70, 130, 23, 37),      # odd sizes, ragged channel counts, tiles spanning batch entries
+    (1, 6, 5, 45, 31),         # fewer channels than a tile on both sides
+]
+
+
+@pytest.mark.parametrize("transpose", [0, 1])
+@pytest.mark.parametrize("B,cin,cout,H,W", WINO_CASES)
+def test_winograd_vs_oracle(L, B, cin, cout, H, W, transpose):
+    """g2s_conv3x3_wino (transformed weights from g2s_wino_weights) against the direct-convolution
+    oracle, forward and data-gradient form, library split-K and forced 1 / 3, with and without the
+    style / demodulation scales; same tolerance as the direct kernel."""
+    from gan2shape_amd import modconv as mc
+    rng = np.random.default_rng(B + cin + cout + H + W + transpose)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+    cx, cy = (cout, cin) if transpose else (cin, cout)
+    x = rng.standard_normal((B, cx, H, W)).astype(np.float32)
+    s_in = (1 + 0.3 * rng.standard_normal((B, cx))).astype(np.float32)
+    s_out = None if transpose else (1 + 0.3 * rng.standard_normal((B, cy))).astype(np.float32)
+    exp = expected_modconv(x, w, s_in, s_out, PLAIN, transpose)
+    exp_plain = expected_modconv(x, w, None, None, PLAIN, transpose)
+    xd, wd, sid = dev(x), dev(w), dev(s_in)
+    sod = None if s_out is None else dev(s_out)
+    saved = (mc.WINOGRAD, mc.WINO_MIN_TILES, mc.WINO_SPLITK)
+    try:
+        mc.WINOGRAD, mc.WINO_MIN_TILES = True, 1
+        for sk in (0, 1, 3):
+            mc.WINO_SPLITK = sk
+            assert mc.wino_eligible(xd, wd, PLAIN, H, W)
+            _check(mc.modconv_raw(xd, wd, sid, sod, PLAIN, transpose), exp, cx * 9, f"winograd split-K {sk}")
+        mc.WINO_SPLITK = 0
+        _check(mc.modconv_raw(xd, wd, None, None, PLAIN, transpose), exp_plain, cx * 9, "winograd, no scales")
+    finally:
+        mc.WINOGRAD, mc.WINO_MIN_TILES, mc.WINO_SPLITK = saved
+
+
+def test_winograd_weights_follow_the_tensor_version(L):
+    """The transformed weights are cached per (tensor, version): an in-place update of the weights
+    (a different checkpoint loaded into the same module) must be seen."""
+    from gan2shape_amd import modconv as mc
+    torch.manual_seed(0)
+    x = torch.randn(8, 64, 32, 32, device="cuda")
+    w = torch.randn(64, 64, 3, 3, device="cuda") / 24
+    saved = mc.WINOGRAD
+    try:
+        mc.WINOGRAD = True
+        y0 = mc.modconv_raw(x, w, None, None, PLAIN, 0)
+        w.mul_(2.0)
+        y1 = mc.modconv_raw(x, w, None, None, PLAIN, 0)
+        torch.testing.assert_close(y1, 2 * y0, rtol=1e-5, atol=1e-5)
+        mc.WINOGRAD = False
+        torch.testing.assert_close(mc.modconv_raw(x, w, None, None, PLAIN, 0), y1, rtol=1e-4, atol=1e-4)
+    finally:
+        mc.WINOGRAD = saved
