@@ -15,8 +15,10 @@
 // implicit GEMM.
 //
 //   * U = G g G^T is computed ONCE per weight tensor (g2s_wino_weights; the weights of G / D / VGG
-//     are constants of the training step) into a tiled layout [m-tile][k-tile][p][4 ch][64 m], so a
-//     K tile of one m-tile is one contiguous 16 KB block: staged with 16-byte loads / LDS writes.
+//     are constants of the training step) into a tiled layout [m-tile][k-tile][i][4 ch][64 m][j]
+//     (p = 4i + j), so a K tile of one m-tile is one contiguous 16 KB block in exactly its LDS
+//     order: it goes global -> LDS by direct DMA (global_load_lds_dwordx4: no registers, no
+//     VGPR->LDS transfer), and one ds_read_b128 fetches the MFMA operands of 4 positions.
 //   * V = B^T d B is never materialised in memory: each thread gathers the 4x4 patch of one
 //     (tile, channel) from global memory (buffer loads with loop-invariant offsets; the hardware
 //     range check supplies the zero padding), applies the style scale, transforms in registers and
@@ -114,10 +116,35 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
         }
         if (valid) offS = (b * d.Cr + kc) * 4;
     }
-    const int offU = tid * 16;  // bytes: float4 number tid (+ 256 per e) of the 16 KB block
+    // U block of K tile kt -> LDS buffer `buf` by direct DMA: 16 wave-instructions of 1 KB, 4 per wave
+    const char *ubase = reinterpret_cast<const char *>(d.U) + (size_t)mt * d.ktiles * WBLOCK * 4 + lane * 16;
+    auto dma_u = [&](int kt, int buf) {
+        const char *src = ubase + (size_t)kt * WBLOCK * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int chunk = e * 4 + wave;   // 1 KB chunk of the 16 KB block
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + chunk * 1024),
+                (__attribute__((address_space(3))) void *)(&Us[0][0] + buf * (16 * WKC * WBM) + chunk * 256), 16, 0, 0);
+        }
+    };
 
     float rd[16], rs = 1.0f;    // FAST: rd[i*4+1], rd[i*4+2] hold the loaded middle columns
     f32x4 ru4[4];
+    const int offU = tid * 16;
+    auto load_u = [&](int kt) {
+        const int su = (mt * d.ktiles + kt) * WBLOCK * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ru, offU + e * 4096, su, 0);
+            ru4[e] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        }
+    };
+    auto store_u = [&](int buf) {
+        f32x4 *ub = reinterpret_cast<f32x4 *>(&Us[0][0] + buf * (16 * WKC * WBM)) + tid;
+#pragma unroll
+        for (int e = 0; e < 4; e++) ub[e * 256] = ru4[e];
+    };
     auto load_tile = [&](int kt) {
         // surplus channels of the last tile: an out-of-range offset makes the hardware return 0
         const int kill = (PARTIAL && kt * WKC + kc >= d.Cr) ? OOB : 0;  // wave-uniform
@@ -136,23 +163,19 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
         }
         if constexpr (SCALE)
             rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, offS | kill, kt * WKC * 4, 0));
-        const int su = (mt * d.ktiles + kt) * WBLOCK * 4;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ru, offU + e * 4096, su, 0);
-            ru4[e] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-        }
     };
-    // B^T d B of the registers -> the 16 planes of buffer `buf`; U block -> buffer `buf`
+    // B^T d B of the registers -> the 16 planes of buffer `buf`, as [i][channel][tile][j]
     auto stage_tile = [&](int buf) {
         float t[16];
         if constexpr (FAST) {
-            // outer columns from the neighbour tiles of the same tile row (zero at the image border)
+            // outer columns from the neighbour lanes = neighbour tiles of the same tile row (whole-wave
+            // DPP shifts: no LDS traffic); zero at the image border
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float left = __shfl_up(rd[i * 4 + 2], 1, 64), right = __shfl_down(rd[i * 4 + 1], 1, 64);
-                rd[i * 4 + 0] = first_col ? 0.0f : left;
-                rd[i * 4 + 3] = last_col ? 0.0f : right;
+                const int left = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rd[i * 4 + 2]), 0x138, 0xf, 0xf, false);
+                const int right = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rd[i * 4 + 1]), 0x130, 0xf, 0xf, false);
+                rd[i * 4 + 0] = first_col ? 0.0f : __builtin_bit_cast(float, left);
+                rd[i * 4 + 3] = last_col ? 0.0f : __builtin_bit_cast(float, right);
             }
         }
         if constexpr (SCALE) {
@@ -166,17 +189,11 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
             t[2 * 4 + j] = rd[2 * 4 + j] - rd[1 * 4 + j];
             t[3 * 4 + j] = rd[1 * 4 + j] - rd[3 * 4 + j];
         }
-        float *vb = &Vs[0][kc * WBT + lane] + buf * (16 * WKC * WBT);
+        f32x4 *vb = reinterpret_cast<f32x4 *>(&Vs[0][0] + buf * (16 * WKC * WBT)) + kc * WBT + lane;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            vb[(i * 4 + 0) * WKC * WBT] = t[i * 4 + 0] - t[i * 4 + 2];
-            vb[(i * 4 + 1) * WKC * WBT] = t[i * 4 + 1] + t[i * 4 + 2];
-            vb[(i * 4 + 2) * WKC * WBT] = t[i * 4 + 2] - t[i * 4 + 1];
-            vb[(i * 4 + 3) * WKC * WBT] = t[i * 4 + 1] - t[i * 4 + 3];
-        }
-        f32x4 *ub = reinterpret_cast<f32x4 *>(&Us[0][0] + buf * (16 * WKC * WBM)) + tid;
-#pragma unroll
-        for (int e = 0; e < 4; e++) ub[e * 256] = ru4[e];
+        for (int i = 0; i < 4; i++)
+            vb[i * WKC * WBT] = f32x4{t[i * 4 + 0] - t[i * 4 + 2], t[i * 4 + 1] + t[i * 4 + 2],
+                                      t[i * 4 + 2] - t[i * 4 + 1], t[i * 4 + 1] - t[i * 4 + 3]};
     };
 
     f32x16 acc[16];
@@ -186,49 +203,70 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
         for (int r = 0; r < 16; r++) acc[p][r] = 0.0f;
 
     const int kt_last = kt_end - 1;
-    const int aoff = lk * WBM + wm * 32 + l31;   // + (p * WKC + 2 ks) * WBM
+    // operand fragments of one k-step (2 channels): one 16-byte read per operand and patch row i
+    const int aoff = lk * WBM + wm * 32 + l31;   // float4 index; + (i * WKC + 2 ks) * WBM
     const int boff = lk * WBT + wn * 32 + l31;
-    // operand fragments of one k-step (2 channels) of all 16 positions
-    float fa0[16], fb0[16], fa1[16], fb1[16];
-    auto read_frags = [&](int buf, const int ks, float (&fa)[16], float (&fb)[16]) {
-        const float *ua = &Us[0][aoff] + buf * (16 * WKC * WBM);
-        const float *vb = &Vs[0][boff] + buf * (16 * WKC * WBT);
+    f32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+    auto read_frags = [&](int buf, const int ks, f32x4 (&fa)[4], f32x4 (&fb)[4]) {
+        const f32x4 *ua = reinterpret_cast<const f32x4 *>(&Us[0][0] + buf * (16 * WKC * WBM)) + aoff;
+        const f32x4 *vb = reinterpret_cast<const f32x4 *>(&Vs[0][0] + buf * (16 * WKC * WBT)) + boff;
 #pragma unroll
-        for (int p = 0; p < 16; p++) {
-            fa[p] = ua[(p * WKC + 2 * ks) * WBM];
-            fb[p] = vb[(p * WKC + 2 * ks) * WBT];
+        for (int i = 0; i < 4; i++) {
+            fa[i] = ua[(i * WKC + 2 * ks) * WBM];
+            fb[i] = vb[(i * WKC + 2 * ks) * WBT];
         }
     };
 
+    load_u(kt_begin);
     load_tile(kt_begin);
     stage_tile(0);
+    store_u(0);
+    load_u(min(kt_begin + 1, kt_last));
     load_tile(min(kt_begin + 1, kt_last));
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     read_frags(0, 0, fa0, fb0);
 
     // Software pipeline of one K tile (ONE loop body: the 256 accumulator registers must not be
-    // shuffled between copies of the body):
-    //   phase 1  MFMAs of k-step 0 (fragments read at the end of the previous iteration), while the
-    //            fragments of k-step 1 are read, tile kt+1 (in registers since the previous
-    //            iteration: a full MFMA phase of latency budget) is transformed and written to the
-    //            free buffer, and the registers are re-loaded with tile kt+2;
-    //   phase 2  12 MFMAs of k-step 1; LDS hand-over (raw barrier: a __syncthreads() would drain the
-    //            global loads just issued); read the k-step-0 fragments of tile kt+1 under the last
-    //            4 MFMAs of k-step 1, so that the matrix pipe does not wait for LDS after the barrier.
+    // shuffled between copies of the body).  A wave issues in order and a second MFMA waits ~64
+    // cycles for the matrix pipe, so everything else sits BETWEEN the MFMAs:
+    //   * the U block of tile kt+1 goes to the free LDS buffer by DMA, tile kt+1's patch (in
+    //     registers since the previous iteration: a full MFMA phase of latency budget) is
+    //     transformed and written there, and the registers are re-loaded with tile kt+2;
+    //   * the fragments of k-step 1 are read under the MFMAs of k-step 0;
+    //   * after the hand-over barrier the k-step-0 fragments of tile kt+1 are read under the last 4
+    //     MFMAs of k-step 1, so that the matrix pipe does not wait for LDS after the barrier.
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; kt++, cur ^= 1) {
         read_frags(cur, 1, fa1, fb1);
         stage_tile(cur ^ 1);
+        store_u(cur ^ 1);
+        load_u(min(kt + 2, kt_last));
         load_tile(min(kt + 2, kt_last));
 #pragma unroll
-        for (int p = 0; p < 16; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[p], fb0[p], acc[p], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int p = 0; p < 16; p++)
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[p >> 2][p & 3], fb0[p >> 2][p & 3], acc[p], 0, 0, 0);
 #pragma unroll
-        for (int p = 0; p < 12; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p], fb1[p], acc[p], 0, 0, 0);
+        for (int p = 0; p < 12; p++)
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p >> 2][p & 3], fb1[p >> 2][p & 3], acc[p], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 28; g++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+            if (g < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (fragments of k-step 1)
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // VALU
+            if (g >= 10 && g < 18) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+            if (g < 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+        // every load issued above (DMA of U, patch of tile kt+2) has had the MFMA phase to land
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         read_frags(cur ^ 1, 0, fa0, fb0);
 #pragma unroll
-        for (int p = 12; p < 16; p++) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p], fb1[p], acc[p], 0, 0, 0);
+        for (int p = 12; p < 16; p++)
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p >> 2][p & 3], fb1[p >> 2][p & 3], acc[p], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);      // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);      // DS read (k-step-0 fragments of tile kt+1)
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -298,17 +336,15 @@ __global__ void wino_weights_kernel(const float *w, float *U, int M, int Cr, int
         h[2 * 3 + j] = 0.5f * (g[0 * 3 + j] - g[1 * 3 + j] + g[2 * 3 + j]);
         h[3 * 3 + j] = g[2 * 3 + j];
     }
-    float *dst = U + ((size_t)((m / WBM) * ktiles + c / WKC) * 16 * WKC + (c % WKC)) * WBM + (m % WBM);
+    // block [i][channel][m][j] (p = 4 i + j): row i of G g G^T is one float4
+    f32x4 *dst = reinterpret_cast<f32x4 *>(U + (size_t)((m / WBM) * ktiles + c / WKC) * WBLOCK) + (c % WKC) * WBM + (m % WBM);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const float u0 = h[i * 3 + 0];
         const float u1 = 0.5f * (h[i * 3 + 0] + h[i * 3 + 1] + h[i * 3 + 2]);
         const float u2 = 0.5f * (h[i * 3 + 0] - h[i * 3 + 1] + h[i * 3 + 2]);
         const float u3 = h[i * 3 + 2];
-        dst[(size_t)(i * 4 + 0) * WKC * WBM] = u0;
-        dst[(size_t)(i * 4 + 1) * WKC * WBM] = u1;
-        dst[(size_t)(i * 4 + 2) * WKC * WBM] = u2;
-        dst[(size_t)(i * 4 + 3) * WKC * WBM] = u3;
+        dst[i * WKC * WBM] = f32x4{u0, u1, u2, u3};
     }
 }
 
