@@ -54,6 +54,8 @@ struct WinoDesc {
     int B, Cr, M, H, W;
     int TH, TW;          // tiles per image (ceil(H/2), ceil(W/2))
     int ktiles, splitk;
+    int upw;             // stream-K: K-tile units per workgroup (0 = one (tile, K slice) per workgroup)
+    int units;           // stream-K: tiles * ktiles
     int act;
     float act_alpha, act_gain;
 };
@@ -71,13 +73,24 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lk = lane >> 5;
     const int tiles_m = (d.M + WBM - 1) / WBM;
-    const int tile_id = xcd_logical_tile();
-    const int mt = tile_id % tiles_m, nt = tile_id / tiles_m;
     const int per_img = d.TH * d.TW, Ntiles = d.B * per_img;
-    if (nt * WBT >= Ntiles) return;
-    const int per = (d.ktiles + d.splitk - 1) / d.splitk;
-    const int kt_begin = blockIdx.y * per, kt_end = min(d.ktiles, kt_begin + per);
-    if (kt_begin >= kt_end) return;
+    // Work of this workgroup: a run of (tile, K tile) units.  Plain mode: one tile, one K slice
+    // (blockIdx.y of split-K).  Stream-K mode: an equal share of ALL units, crossing tile borders —
+    // every CU gets the same amount of matrix work whatever the tile count (one workgroup per CU
+    // fits: a launch of 1.1 rounds of equal tiles would otherwise take 2).
+    int unit, unit_end;
+    {
+        const int g = xcd_logical_tile();
+        if (d.upw) {
+            unit = g * d.upw;
+            unit_end = min(d.units, unit + d.upw);
+        } else {
+            const int per = (d.ktiles + d.splitk - 1) / d.splitk;
+            const int k0 = blockIdx.y * per;
+            unit = g * d.ktiles + k0;
+            unit_end = g * d.ktiles + min(d.ktiles, k0 + per);
+        }
+    }
     const int HW = d.H * d.W;
     constexpr int OOB = 0x7fffffff;
 
@@ -86,233 +99,242 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
     const auto rsc = __builtin_amdgcn_make_buffer_rsrc((void *)(SCALE ? d.in_scale : d.x), 0,
                                                        SCALE ? d.B * d.Cr * 4 : 4, 0x00020000);
 
-    // ---- input patch of this thread: tile t = lane of the block, channel kc = wave of the K tile
     const int kc = wave;
-    constexpr int ND = FAST ? 4 : 16;   // loads per patch
-    int offD[ND];
-    int offS = OOB;
-    bool first_col = false, last_col = false;
-    {
-        const int n = nt * WBT + lane;
-        const bool valid = n < Ntiles;
-        const int b = valid ? n / per_img : 0, r = valid ? n % per_img : 0;
-        const int ty = r / d.TW, tx = r % d.TW;
-        const int base = (b * d.Cr + kc) * HW;
-        first_col = tx == 0;
-        last_col = tx == d.TW - 1;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int iy = 2 * ty - 1 + i;
-            const bool row_ok = valid & (iy >= 0) & (iy < d.H);
-            if constexpr (FAST) {
-                offD[i] = row_ok ? (base + iy * d.W + 2 * tx) * 4 : OOB;   // columns 2tx, 2tx+1
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int ix = 2 * tx - 1 + j;
-                    offD[i * 4 + j] = (row_ok & (ix >= 0) & (ix < d.W)) ? (base + iy * d.W + ix) * 4 : OOB;
+    while (unit < unit_end) {
+        const int tile_id = unit / d.ktiles;
+        const int kt_begin = unit - tile_id * d.ktiles;
+        const int kt_end = min(d.ktiles, kt_begin + (unit_end - unit));
+        unit += kt_end - kt_begin;
+        const int mt = tile_id % tiles_m, nt = tile_id / tiles_m;
+        __syncthreads();   // the previous segment's LDS reads are done before this one's staging
+        // ---- input patch of this thread: tile t = lane of the block, channel kc = wave of the K tile
+        constexpr int ND = FAST ? 4 : 16;   // loads per patch
+        int offD[ND];
+        int offS = OOB;
+        bool first_col = false, last_col = false;
+        {
+            const int n = nt * WBT + lane;
+            const bool valid = n < Ntiles;
+            const int b = valid ? n / per_img : 0, r = valid ? n % per_img : 0;
+            const int ty = r / d.TW, tx = r % d.TW;
+            const int base = (b * d.Cr + kc) * HW;
+            first_col = tx == 0;
+            last_col = tx == d.TW - 1;
+    #pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int iy = 2 * ty - 1 + i;
+                const bool row_ok = valid & (iy >= 0) & (iy < d.H);
+                if constexpr (FAST) {
+                    offD[i] = row_ok ? (base + iy * d.W + 2 * tx) * 4 : OOB;   // columns 2tx, 2tx+1
+                } else {
+    #pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int ix = 2 * tx - 1 + j;
+                        offD[i * 4 + j] = (row_ok & (ix >= 0) & (ix < d.W)) ? (base + iy * d.W + ix) * 4 : OOB;
+                    }
                 }
             }
+            if (valid) offS = (b * d.Cr + kc) * 4;
         }
-        if (valid) offS = (b * d.Cr + kc) * 4;
-    }
-    // U block of K tile kt -> LDS buffer `buf` by direct DMA: 16 wave-instructions of 1 KB, 4 per wave
-    const char *ubase = reinterpret_cast<const char *>(d.U) + (size_t)mt * d.ktiles * WBLOCK * 4 + lane * 16;
-    auto dma_u = [&](int kt, int buf) {
-        const char *src = ubase + (size_t)kt * WBLOCK * 4;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int chunk = e * 4 + wave;   // 1 KB chunk of the 16 KB block
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(src + chunk * 1024),
-                (__attribute__((address_space(3))) void *)(&Us[0][0] + buf * (16 * WKC * WBM) + chunk * 256), 16, 0, 0);
-        }
-    };
-
-    float rd[16], rs = 1.0f;    // FAST: rd[i*4+1], rd[i*4+2] hold the loaded middle columns
-    f32x4 ru4[4];
-    const int offU = tid * 16;
-    auto load_u = [&](int kt) {
-        const int su = (mt * d.ktiles + kt) * WBLOCK * 4;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ru, offU + e * 4096, su, 0);
-            ru4[e] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-        }
-    };
-    auto store_u = [&](int buf) {
-        f32x4 *ub = reinterpret_cast<f32x4 *>(&Us[0][0] + buf * (16 * WKC * WBM)) + tid;
-#pragma unroll
-        for (int e = 0; e < 4; e++) ub[e * 256] = ru4[e];
-    };
-    auto load_tile = [&](int kt) {
-        // surplus channels of the last tile: an out-of-range offset makes the hardware return 0
-        const int kill = (PARTIAL && kt * WKC + kc >= d.Cr) ? OOB : 0;  // wave-uniform
-        const int so = kt * WKC * HW * 4;
-        if constexpr (FAST) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rx, offD[i] | kill, so, 0);
-                rd[i * 4 + 1] = __uint_as_float(v.x);
-                rd[i * 4 + 2] = __uint_as_float(v.y);
+        // U block of K tile kt -> LDS buffer `buf` by direct DMA: 16 wave-instructions of 1 KB, 4 per wave
+        const char *ubase = reinterpret_cast<const char *>(d.U) + (size_t)mt * d.ktiles * WBLOCK * 4 + lane * 16;
+        auto dma_u = [&](int kt, int buf) {
+            const char *src = ubase + (size_t)kt * WBLOCK * 4;
+    #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int chunk = e * 4 + wave;   // 1 KB chunk of the 16 KB block
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + chunk * 1024),
+                    (__attribute__((address_space(3))) void *)(&Us[0][0] + buf * (16 * WKC * WBM) + chunk * 256), 16, 0, 0);
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; e++)
-                rd[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, offD[e] | kill, so, 0));
-        }
-        if constexpr (SCALE)
-            rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, offS | kill, kt * WKC * 4, 0));
-    };
-    // B^T d B of the registers -> the 16 planes of buffer `buf`, as [i][channel][tile][j]
-    auto stage_tile = [&](int buf) {
-        float t[16];
-        if constexpr (FAST) {
-            // outer columns from the neighbour lanes = neighbour tiles of the same tile row (whole-wave
-            // DPP shifts: no LDS traffic); zero at the image border
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int left = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rd[i * 4 + 2]), 0x138, 0xf, 0xf, false);
-                const int right = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rd[i * 4 + 1]), 0x130, 0xf, 0xf, false);
-                rd[i * 4 + 0] = first_col ? 0.0f : __builtin_bit_cast(float, left);
-                rd[i * 4 + 3] = last_col ? 0.0f : __builtin_bit_cast(float, right);
+        };
+
+        float rd[16], rs = 1.0f;    // FAST: rd[i*4+1], rd[i*4+2] hold the loaded middle columns
+        f32x4 ru4[4];
+        const int offU = tid * 16;
+        auto load_u = [&](int kt) {
+            const int su = (mt * d.ktiles + kt) * WBLOCK * 4;
+    #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ru, offU + e * 4096, su, 0);
+                ru4[e] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
             }
-        }
-        if constexpr (SCALE) {
-#pragma unroll
-            for (int e = 0; e < 16; e++) rd[e] *= rs;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            t[0 * 4 + j] = rd[0 * 4 + j] - rd[2 * 4 + j];
-            t[1 * 4 + j] = rd[1 * 4 + j] + rd[2 * 4 + j];
-            t[2 * 4 + j] = rd[2 * 4 + j] - rd[1 * 4 + j];
-            t[3 * 4 + j] = rd[1 * 4 + j] - rd[3 * 4 + j];
-        }
-        f32x4 *vb = reinterpret_cast<f32x4 *>(&Vs[0][0] + buf * (16 * WKC * WBT)) + kc * WBT + lane;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            vb[i * WKC * WBT] = f32x4{t[i * 4 + 0] - t[i * 4 + 2], t[i * 4 + 1] + t[i * 4 + 2],
-                                      t[i * 4 + 2] - t[i * 4 + 1], t[i * 4 + 1] - t[i * 4 + 3]};
-    };
+        };
+        auto store_u = [&](int buf) {
+            f32x4 *ub = reinterpret_cast<f32x4 *>(&Us[0][0] + buf * (16 * WKC * WBM)) + tid;
+    #pragma unroll
+            for (int e = 0; e < 4; e++) ub[e * 256] = ru4[e];
+        };
+        auto load_tile = [&](int kt) {
+            // surplus channels of the last tile: an out-of-range offset makes the hardware return 0
+            const int kill = (PARTIAL && kt * WKC + kc >= d.Cr) ? OOB : 0;  // wave-uniform
+            const int so = kt * WKC * HW * 4;
+            if constexpr (FAST) {
+    #pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rx, offD[i] | kill, so, 0);
+                    rd[i * 4 + 1] = __uint_as_float(v.x);
+                    rd[i * 4 + 2] = __uint_as_float(v.y);
+                }
+            } else {
+    #pragma unroll
+                for (int e = 0; e < 16; e++)
+                    rd[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, offD[e] | kill, so, 0));
+            }
+            if constexpr (SCALE)
+                rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, offS | kill, kt * WKC * 4, 0));
+        };
+        // B^T d B of the registers -> the 16 planes of buffer `buf`, as [i][channel][tile][j]
+        auto stage_tile = [&](int buf) {
+            float t[16];
+            if constexpr (FAST) {
+                // outer columns from the neighbour lanes = neighbour tiles of the same tile row (whole-wave
+                // DPP shifts: no LDS traffic); zero at the image border
+    #pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int left = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rd[i * 4 + 2]), 0x138, 0xf, 0xf, false);
+                    const int right = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rd[i * 4 + 1]), 0x130, 0xf, 0xf, false);
+                    rd[i * 4 + 0] = first_col ? 0.0f : __builtin_bit_cast(float, left);
+                    rd[i * 4 + 3] = last_col ? 0.0f : __builtin_bit_cast(float, right);
+                }
+            }
+            if constexpr (SCALE) {
+    #pragma unroll
+                for (int e = 0; e < 16; e++) rd[e] *= rs;
+            }
+    #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                t[0 * 4 + j] = rd[0 * 4 + j] - rd[2 * 4 + j];
+                t[1 * 4 + j] = rd[1 * 4 + j] + rd[2 * 4 + j];
+                t[2 * 4 + j] = rd[2 * 4 + j] - rd[1 * 4 + j];
+                t[3 * 4 + j] = rd[1 * 4 + j] - rd[3 * 4 + j];
+            }
+            f32x4 *vb = reinterpret_cast<f32x4 *>(&Vs[0][0] + buf * (16 * WKC * WBT)) + kc * WBT + lane;
+    #pragma unroll
+            for (int i = 0; i < 4; i++)
+                vb[i * WKC * WBT] = f32x4{t[i * 4 + 0] - t[i * 4 + 2], t[i * 4 + 1] + t[i * 4 + 2],
+                                          t[i * 4 + 2] - t[i * 4 + 1], t[i * 4 + 1] - t[i * 4 + 3]};
+        };
 
-    f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; p++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[p][r] = 0.0f;
-
-    const int kt_last = kt_end - 1;
-    // operand fragments of one k-step (2 channels): one 16-byte read per operand and patch row i
-    const int aoff = lk * WBM + wm * 32 + l31;   // float4 index; + (i * WKC + 2 ks) * WBM
-    const int boff = lk * WBT + wn * 32 + l31;
-    f32x4 fa0[4], fb0[4], fa1[4], fb1[4];
-    auto read_frags = [&](int buf, const int ks, f32x4 (&fa)[4], f32x4 (&fb)[4]) {
-        const f32x4 *ua = reinterpret_cast<const f32x4 *>(&Us[0][0] + buf * (16 * WKC * WBM)) + aoff;
-        const f32x4 *vb = reinterpret_cast<const f32x4 *>(&Vs[0][0] + buf * (16 * WKC * WBT)) + boff;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            fa[i] = ua[(i * WKC + 2 * ks) * WBM];
-            fb[i] = vb[(i * WKC + 2 * ks) * WBT];
-        }
-    };
-
-    load_u(kt_begin);
-    load_tile(kt_begin);
-    stage_tile(0);
-    store_u(0);
-    load_u(min(kt_begin + 1, kt_last));
-    load_tile(min(kt_begin + 1, kt_last));
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    read_frags(0, 0, fa0, fb0);
-
-    // Software pipeline of one K tile (ONE loop body: the 256 accumulator registers must not be
-    // shuffled between copies of the body).  A wave issues in order and a second MFMA waits ~64
-    // cycles for the matrix pipe, so everything else sits BETWEEN the MFMAs:
-    //   * the U block of tile kt+1 goes to the free LDS buffer by DMA, tile kt+1's patch (in
-    //     registers since the previous iteration: a full MFMA phase of latency budget) is
-    //     transformed and written there, and the registers are re-loaded with tile kt+2;
-    //   * the fragments of k-step 1 are read under the MFMAs of k-step 0;
-    //   * after the hand-over barrier the k-step-0 fragments of tile kt+1 are read under the last 4
-    //     MFMAs of k-step 1, so that the matrix pipe does not wait for LDS after the barrier.
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; kt++, cur ^= 1) {
-        read_frags(cur, 1, fa1, fb1);
-        stage_tile(cur ^ 1);
-        store_u(cur ^ 1);
-        load_u(min(kt + 2, kt_last));
-        load_tile(min(kt + 2, kt_last));
-#pragma unroll
+        f32x16 acc[16];
+    #pragma unroll
         for (int p = 0; p < 16; p++)
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[p >> 2][p & 3], fb0[p >> 2][p & 3], acc[p], 0, 0, 0);
-#pragma unroll
-        for (int p = 0; p < 12; p++)
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p >> 2][p & 3], fb1[p >> 2][p & 3], acc[p], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 28; g++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-            if (g < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (fragments of k-step 1)
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // VALU
-            if (g >= 10 && g < 18) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-            if (g < 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-        }
-        // every load issued above (DMA of U, patch of tile kt+2) has had the MFMA phase to land
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        read_frags(cur ^ 1, 0, fa0, fb0);
-#pragma unroll
-        for (int p = 12; p < 16; p++)
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p >> 2][p & 3], fb1[p >> 2][p & 3], acc[p], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);      // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);      // DS read (k-step-0 fragments of tile kt+1)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    #pragma unroll
+            for (int r = 0; r < 16; r++) acc[p][r] = 0.0f;
 
-    // ---- epilogue: output transform A^T M A in registers, scale / bias / activation, store.
-    // C layout of the 32x32 MFMA: row m = (r & 3) + 8 (r >> 2) + 4 lk, column n = l31.
-    const int n = nt * WBT + wn * 32 + l31;
-    if (n >= Ntiles) return;
-    const int b = n / per_img, rr = n % per_img;
-    const int oy = 2 * (rr / d.TW), ox = 2 * (rr % d.TW);
-    const bool row1 = oy + 1 < d.H, col1 = ox + 1 < d.W;
-    const bool vec = col1 && (d.W & 1) == 0 && d.splitk == 1;
-    float *yb = d.y + ((size_t)b * d.M * d.H + oy) * d.W + ox;
-    const float *ob = d.out_scale ? d.out_scale + (size_t)b * d.M : nullptr;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int m = mt * WBM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (m >= d.M) continue;
-        float s0[4], s1[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            s0[j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
-            s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+        const int kt_last = kt_end - 1;
+        // operand fragments of one k-step (2 channels): one 16-byte read per operand and patch row i
+        const int aoff = lk * WBM + wm * 32 + l31;   // float4 index; + (i * WKC + 2 ks) * WBM
+        const int boff = lk * WBT + wn * 32 + l31;
+        f32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+        auto read_frags = [&](int buf, const int ks, f32x4 (&fa)[4], f32x4 (&fb)[4]) {
+            const f32x4 *ua = reinterpret_cast<const f32x4 *>(&Us[0][0] + buf * (16 * WKC * WBM)) + aoff;
+            const f32x4 *vb = reinterpret_cast<const f32x4 *>(&Vs[0][0] + buf * (16 * WKC * WBT)) + boff;
+    #pragma unroll
+            for (int i = 0; i < 4; i++) {
+                fa[i] = ua[(i * WKC + 2 * ks) * WBM];
+                fb[i] = vb[(i * WKC + 2 * ks) * WBT];
+            }
+        };
+
+        load_u(kt_begin);
+        load_tile(kt_begin);
+        stage_tile(0);
+        store_u(0);
+        load_u(min(kt_begin + 1, kt_last));
+        load_tile(min(kt_begin + 1, kt_last));
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        read_frags(0, 0, fa0, fb0);
+
+        // Software pipeline of one K tile (ONE loop body: the 256 accumulator registers must not be
+        // shuffled between copies of the body).  A wave issues in order and a second MFMA waits ~64
+        // cycles for the matrix pipe, so everything else sits BETWEEN the MFMAs:
+        //   * the U block of tile kt+1 goes to the free LDS buffer by DMA, tile kt+1's patch (in
+        //     registers since the previous iteration: a full MFMA phase of latency budget) is
+        //     transformed and written there, and the registers are re-loaded with tile kt+2;
+        //   * the fragments of k-step 1 are read under the MFMAs of k-step 0;
+        //   * after the hand-over barrier the k-step-0 fragments of tile kt+1 are read under the last 4
+        //     MFMAs of k-step 1, so that the matrix pipe does not wait for LDS after the barrier.
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end; kt++, cur ^= 1) {
+            read_frags(cur, 1, fa1, fb1);
+            stage_tile(cur ^ 1);
+            store_u(cur ^ 1);
+            load_u(min(kt + 2, kt_last));
+            load_tile(min(kt + 2, kt_last));
+    #pragma unroll
+            for (int p = 0; p < 16; p++)
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[p >> 2][p & 3], fb0[p >> 2][p & 3], acc[p], 0, 0, 0);
+    #pragma unroll
+            for (int p = 0; p < 12; p++)
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p >> 2][p & 3], fb1[p >> 2][p & 3], acc[p], 0, 0, 0);
+    #pragma unroll
+            for (int g = 0; g < 28; g++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                if (g < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (fragments of k-step 1)
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // VALU
+                if (g >= 10 && g < 18) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+                if (g < 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+            }
+            // every load issued above (DMA of U, patch of tile kt+2) has had the MFMA phase to land
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            read_frags(cur ^ 1, 0, fa0, fb0);
+    #pragma unroll
+            for (int p = 12; p < 16; p++)
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p >> 2][p & 3], fb1[p >> 2][p & 3], acc[p], 0, 0, 0);
+    #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);      // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);      // DS read (k-step-0 fragments of tile kt+1)
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        float y[4] = {s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
-        const float sc = ob ? ob[m] : 1.0f;
-        const float bi = d.bias ? d.bias[m] : 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            float v = y[q] * sc + bi;
-            if (d.act) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
-            y[q] = v;
-        }
-        float *dst = yb + (size_t)m * HW;
-        if (vec) {
-            *reinterpret_cast<float2 *>(dst) = float2{y[0], y[1]};
-            if (row1) *reinterpret_cast<float2 *>(dst + d.W) = float2{y[2], y[3]};
-        } else if (d.splitk > 1) {
-            unsafeAtomicAdd(dst, y[0]);
-            if (col1) unsafeAtomicAdd(dst + 1, y[1]);
-            if (row1) unsafeAtomicAdd(dst + d.W, y[2]);
-            if (row1 && col1) unsafeAtomicAdd(dst + d.W + 1, y[3]);
-        } else {
-            dst[0] = y[0];
-            if (col1) dst[1] = y[1];
-            if (row1) dst[d.W] = y[2];
-            if (row1 && col1) dst[d.W + 1] = y[3];
+
+        // ---- epilogue: output transform A^T M A in registers, scale / bias / activation, store.
+        // C layout of the 32x32 MFMA: row m = (r & 3) + 8 (r >> 2) + 4 lk, column n = l31.
+        const int n = nt * WBT + wn * 32 + l31;
+        if (n >= Ntiles) continue;
+        const int b = n / per_img, rr = n % per_img;
+        const int oy = 2 * (rr / d.TW), ox = 2 * (rr % d.TW);
+        const bool row1 = oy + 1 < d.H, col1 = ox + 1 < d.W;
+        const bool split = kt_begin != 0 || kt_end != d.ktiles;   // partial sum of the tile
+        const bool vec = col1 && (d.W & 1) == 0 && !split;
+        float *yb = d.y + ((size_t)b * d.M * d.H + oy) * d.W + ox;
+        const float *ob = d.out_scale ? d.out_scale + (size_t)b * d.M : nullptr;
+    #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = mt * WBM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (m >= d.M) continue;
+            float s0[4], s1[4];
+    #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                s0[j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+                s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+            }
+            float y[4] = {s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
+            const float sc = ob ? ob[m] : 1.0f;
+            const float bi = d.bias ? d.bias[m] : 0.0f;
+    #pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float v = y[q] * sc + bi;
+                if (d.act) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
+                y[q] = v;
+            }
+            float *dst = yb + (size_t)m * HW;
+            if (vec) {
+                *reinterpret_cast<float2 *>(dst) = float2{y[0], y[1]};
+                if (row1) *reinterpret_cast<float2 *>(dst + d.W) = float2{y[2], y[3]};
+            } else if (split) {
+                unsafeAtomicAdd(dst, y[0]);
+                if (col1) unsafeAtomicAdd(dst + 1, y[1]);
+                if (row1) unsafeAtomicAdd(dst + d.W, y[2]);
+                if (row1 && col1) unsafeAtomicAdd(dst + d.W + 1, y[3]);
+            } else {
+                dst[0] = y[0];
+                if (col1) dst[1] = y[1];
+                if (row1) dst[d.W] = y[2];
+                if (row1 && col1) dst[d.W + 1] = y[3];
+            }
         }
     }
 }
@@ -399,21 +421,44 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
     d.act_alpha = alpha;
     d.act_gain = gain;
     const int tiles = cdiv(M, WBM) * cdiv((long)B * d.TH * d.TW, WBT);
-    if (splitk <= 0) {  // fill the 256 CUs (one workgroup per CU: 512 registers per lane)
+    // Partition.  One workgroup per CU is resident (512 registers per lane), all tiles cost the same:
+    // a launch of `tiles` workgroups takes ceil(tiles / 256) rounds.  splitk > 0: that K split of
+    // every tile (tests, tuning).  splitk = 0: whole tiles when the rounds are well filled, else
+    // stream-K — 256 workgroups with equal runs of (tile, K tile) units.
+    constexpr int NCU = 256;
+    int grid_x = tiles;
+    d.upw = 0;
+    d.units = tiles * d.ktiles;
+    bool partial_sums;
+    if (splitk > 0) {
+        splitk = std::min(splitk, d.ktiles);
+        partial_sums = splitk > 1;
+    } else if (splitk < 0) {   // stream-K over -splitk workgroups (tests)
+        d.upw = cdiv(d.units, std::min(-splitk, d.units));
+        grid_x = cdiv(d.units, d.upw);
         splitk = 1;
-        while (tiles * splitk < 256 && d.ktiles / (splitk * 2) >= 8 && splitk < 32) splitk *= 2;
+        partial_sums = true;
+    } else {
+        splitk = 1;
+        const int rounds = cdiv(tiles, NCU);
+        const double fill = (double)tiles / ((double)rounds * NCU);
+        const int upw = cdiv(d.units, NCU);
+        if (fill < 0.9 && upw >= 4) {
+            d.upw = upw;
+            grid_x = cdiv(d.units, upw);
+        }
+        partial_sums = d.upw != 0;
     }
-    splitk = std::max(1, std::min(splitk, d.ktiles));
-    const bool deferred = splitk > 1 && (bias != nullptr || act != 0);
+    const bool deferred = partial_sums && (bias != nullptr || act != 0);
     if (deferred) {
         d.bias = nullptr;
         d.act = 0;
     }
     d.splitk = splitk;
     hipStream_t st = as_stream(stream);
-    if (splitk > 1 && hipMemsetAsync(y, 0, (size_t)B * M * H * W * sizeof(float), st) != hipSuccess)
+    if (partial_sums && hipMemsetAsync(y, 0, (size_t)B * M * H * W * sizeof(float), st) != hipSuccess)
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
-    dim3 grid(tiles, splitk, 1);
+    dim3 grid(grid_x, splitk, 1);
     const bool partial = Cr % WKC != 0;
     // whole tile rows per workgroup and 8-byte aligned row pairs: see FAST above
     const bool fast = d.TW <= WBT && WBT % d.TW == 0 && W % 2 == 0;

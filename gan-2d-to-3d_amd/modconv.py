@@ -61,13 +61,38 @@ def out_size(h, k, mode):
 # workgroups for the 64-channel x 64-tile blocks) stay on the direct kernel.
 WINOGRAD = True
 WINO_MIN_TILES = 512
-WINO_SPLITK = 0   # 0: chosen by the library; tests / tuning tools force a value
+WINO_FORCE = None   # tests / tuning tools: "direct", or a splitk value (0 = library choice) for every 3x3 stride-1 call
 _WINO_U = {}  # (data_ptr, version, shape, transpose) -> (w, U): transformed weights of constant tensors
+
+try:  # measured choices for the workload's own call signatures (tools/tune_wino.py)
+    from .wino_tuned import TABLE as _WINO_TABLE
+except ImportError:
+    _WINO_TABLE = {}
+
+
+def wino_choice(x, w, mode, transpose, fused):
+    """None: direct implicit GEMM; else the `splitk` argument of g2s_conv3x3_wino."""
+    B, Cr, H, W = x.shape
+    if not (WINOGRAD and mode == PLAIN and w.shape[2] == 3 and w.shape[3] == 3 and not w.requires_grad
+            and H >= 2 and W >= 2):
+        return None
+    if WINO_FORCE is not None:
+        return None if WINO_FORCE == "direct" else int(WINO_FORCE)
+    M = w.shape[1] if transpose else w.shape[0]
+    hit = _WINO_TABLE.get((B, Cr, M, H, W, int(transpose), int(fused)))
+    if hit is not None:
+        return None if hit == "direct" else int(hit)
+    # unmeasured signature: Winograd when there is enough work for the 64-channel x 64-tile
+    # workgroups (>= 2 rounds of whole tiles, or stream-K runs of >= 32 K tiles)
+    tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+    blocks = -(-tiles // 64) * -(-M // 64)
+    if tiles < WINO_MIN_TILES or blocks * -(-Cr // 4) < 256 * 32:
+        return None
+    return 0
 
 
 def wino_eligible(x, w, mode, H, W):
-    return (WINOGRAD and mode == PLAIN and w.shape[2] == 3 and w.shape[3] == 3 and not w.requires_grad
-            and H >= 2 and W >= 2 and x.shape[0] * ((H + 1) // 2) * ((W + 1) // 2) >= WINO_MIN_TILES)
+    return wino_choice(x, w, mode, 0, 0) is not None
 
 
 def wino_weights(w, transpose):
@@ -87,7 +112,7 @@ def wino_weights(w, transpose):
     return hit[1]
 
 
-def _wino_launch(x, w, in_scale, out_scale, bias, transpose, act, alpha, gain, y):
+def _wino_launch(x, w, in_scale, out_scale, bias, transpose, act, alpha, gain, y, splitk=0):
     B, Cr, H, W = x.shape
     M = y.shape[1]
     U = wino_weights(w, transpose)
@@ -97,7 +122,7 @@ def _wino_launch(x, w, in_scale, out_scale, bias, transpose, act, alpha, gain, y
                   2.0 * 16 * tiles * M * Cr):
         _lib.check(L.g2s_conv3x3_wino(_lib.ptr(x), _lib.ptr(U), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                       _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W, int(act), float(alpha),
-                                      float(gain), int(WINO_SPLITK), _lib.stream()))
+                                      float(gain), int(splitk), _lib.stream()))
     return y
 
 
@@ -126,8 +151,9 @@ def modconv_raw(x, w, in_scale, out_scale, mode, transpose):
     y = torch.empty((B, cy, oh, ow), dtype=torch.float32, device=x.device)
     si = None if in_scale is None else in_scale.contiguous()
     so = None if out_scale is None else out_scale.contiguous()
-    if wino_eligible(x, w, mode, H, W):
-        return _wino_launch(x, w, si, so, None, transpose, 0, 0.0, 1.0, y)
+    choice = wino_choice(x, w, mode, transpose, 0)
+    if choice is not None:
+        return _wino_launch(x, w, si, so, None, transpose, 0, 0.0, 1.0, y, choice)
     L = _lib.load()
     # algorithmic FLOP: 2 * B * Cout * Cin * k^2 * (spatial positions of the un-strided side);
     # algorithmic bytes: each operand once
@@ -298,8 +324,9 @@ class ConvBiasActFunction(Function):
         Cout, _, k, _ = w.shape
         oh, ow = out_size(H, k, mode), out_size(W, k, mode)
         y = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device)
-        if wino_eligible(x, w, mode, H, W):
-            _wino_launch(x, w, None, None, bias, 0, 1, alpha, gain, y)
+        choice = wino_choice(x, w, mode, 0, 1)
+        if choice is not None:
+            _wino_launch(x, w, None, None, bias, 0, 1, alpha, gain, y, choice)
         else:
             L = _lib.load()
             with profiled(2.0 * B * Cout * Cin * k * k * oh * ow, 4.0 * (x.numel() + w.numel() + y.numel())):

@@ -193,8 +193,11 @@ int g2s_conv2d_wgrad(const float *A, const float *G, float *dw, int B, int Ca, i
  *   (the data-gradient of the forward map).  Done once per weight tensor by the caller.
  * g2s_conv3x3_wino: y[b,m] = act(out_scale[b,m] * sum_c conv3x3(in_scale[b,c] * x[b,c], w(m,c)) + bias[m])
  *   x [B, Cr, H, W], y [B, M, H, W]; in_scale [B, Cr], out_scale [B, M], bias [M] may be NULL;
- *   act 0: none, 1: leaky-ReLU(alpha) * gain.  splitk = 0: chosen by the library (partial sums by
- *   float atomics into a cleared y, epilogue deferred to one elementwise launch).
+ *   act 0: none, 1: leaky-ReLU(alpha) * gain.  splitk = 0: partition chosen by the library — whole
+ *   tiles, or "stream-K": equal runs of (tile, K tile) units over 256 workgroups when whole tiles
+ *   would fill the last round of CUs badly; splitk > 0: that K split of every tile; splitk < 0:
+ *   stream-K over -splitk workgroups.  Partial sums meet by float atomics in a cleared y and the
+ *   bias / activation then runs as one deferred elementwise launch.
  * ---------------------------------------------------------------------------------------- */
 size_t g2s_wino_weights_floats(int M, int Cr);
 int g2s_wino_weights(const float *w, float *U, int Cout, int Cin, int transpose, g2s_stream_t stream);

@@ -95,7 +95,7 @@ def test_modconv_every_tile_vs_oracle(L, B, cin, cout, H, k, mode, transpose):
     K = (cout if transpose else cin) * k * k
     try:
         L.g2s_modconv_tune(-1, -1)
-        _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, "built-in choice (Winograd where eligible)")
+        _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, "built-in choice (measured table: direct / Winograd)")
         with direct_kernel():
             _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, "built-in direct choice")
             for tile in TILES:
@@ -127,7 +127,14 @@ def test_conv_bias_act_every_tile_vs_oracle(L, B, cin, cout, H, alpha, gain):
     # with the absolute tolerance only (|slope difference| * |pre| <= atol)
     xd, wd, bd = dev(x), dev(w), dev(b)
     try:
-        _check(conv_bias_act(xd, wd, bd, PLAIN, alpha, gain), exp, cin * 9, "built-in choice (Winograd)")
+        _check(conv_bias_act(xd, wd, bd, PLAIN, alpha, gain), exp, cin * 9, "built-in choice (measured table)")
+        from gan2shape_amd import modconv as mc
+        for force in (0, 1, -256):      # Winograd with the fused / deferred epilogue: library choice, whole tiles, stream-K
+            mc.WINO_FORCE = force
+            try:
+                _check(conv_bias_act(xd, wd, bd, PLAIN, alpha, gain), exp, cin * 9, f"winograd partition {force}")
+            finally:
+                mc.WINO_FORCE = None
         with direct_kernel():
             for tile, sk in [(-1, -1)] + [(t, s) for t in TILES for s in SPLITS]:
                 assert L.g2s_modconv_tune(tile, sk) == 0
@@ -172,8 +179,8 @@ WINO_CASES = [  # B, Cin, Cout, H, W
 @pytest.mark.parametrize("B,cin,cout,H,W", WINO_CASES)
 def test_winograd_vs_oracle(L, B, cin, cout, H, W, transpose):
     """g2s_conv3x3_wino (transformed weights from g2s_wino_weights) against the direct-convolution
-    oracle, forward and data-gradient form, library split-K and forced 1 / 3, with and without the
-    style / demodulation scales; same tolerance as the direct kernel."""
+    oracle, forward and data-gradient form, every partition (library choice, whole tiles, split-K,
+    stream-K), with and without the style / demodulation scales; same tolerance as the direct kernel."""
     from gan2shape_amd import modconv as mc
     rng = np.random.default_rng(B + cin + cout + H + W + transpose)
     w = (rng.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
@@ -185,17 +192,17 @@ def test_winograd_vs_oracle(L, B, cin, cout, H, W, transpose):
     exp_plain = expected_modconv(x, w, None, None, PLAIN, transpose)
     xd, wd, sid = dev(x), dev(w), dev(s_in)
     sod = None if s_out is None else dev(s_out)
-    saved = (mc.WINOGRAD, mc.WINO_MIN_TILES, mc.WINO_SPLITK)
+    saved = (mc.WINOGRAD, mc.WINO_FORCE)
     try:
-        mc.WINOGRAD, mc.WINO_MIN_TILES = True, 1
-        for sk in (0, 1, 3):
-            mc.WINO_SPLITK = sk
-            assert mc.wino_eligible(xd, wd, PLAIN, H, W)
-            _check(mc.modconv_raw(xd, wd, sid, sod, PLAIN, transpose), exp, cx * 9, f"winograd split-K {sk}")
-        mc.WINO_SPLITK = 0
+        mc.WINOGRAD = True
+        for sk in (0, 1, 3, -7, -256):     # library choice, whole tiles, split-K 3, stream-K over 7 / 256 WGs
+            mc.WINO_FORCE = sk
+            assert mc.wino_choice(xd, wd, PLAIN, transpose, 0) == sk
+            _check(mc.modconv_raw(xd, wd, sid, sod, PLAIN, transpose), exp, cx * 9, f"winograd partition {sk}")
+        mc.WINO_FORCE = 0
         _check(mc.modconv_raw(xd, wd, None, None, PLAIN, transpose), exp_plain, cx * 9, "winograd, no scales")
     finally:
-        mc.WINOGRAD, mc.WINO_MIN_TILES, mc.WINO_SPLITK = saved
+        mc.WINOGRAD, mc.WINO_FORCE = saved
 
 
 def test_winograd_weights_follow_the_tensor_version(L):
@@ -205,14 +212,14 @@ def test_winograd_weights_follow_the_tensor_version(L):
     torch.manual_seed(0)
     x = torch.randn(8, 64, 32, 32, device="cuda")
     w = torch.randn(64, 64, 3, 3, device="cuda") / 24
-    saved = mc.WINOGRAD
+    saved = (mc.WINOGRAD, mc.WINO_FORCE)
     try:
-        mc.WINOGRAD = True
+        mc.WINOGRAD, mc.WINO_FORCE = True, 0
         y0 = mc.modconv_raw(x, w, None, None, PLAIN, 0)
         w.mul_(2.0)
         y1 = mc.modconv_raw(x, w, None, None, PLAIN, 0)
         torch.testing.assert_close(y1, 2 * y0, rtol=1e-5, atol=1e-5)
-        mc.WINOGRAD = False
+        mc.WINO_FORCE = "direct"
         torch.testing.assert_close(mc.modconv_raw(x, w, None, None, PLAIN, 0), y1, rtol=1e-4, atol=1e-4)
     finally:
-        mc.WINOGRAD = saved
+        mc.WINOGRAD, mc.WINO_FORCE = saved

@@ -38,12 +38,11 @@ for B, cin, cout, H in SIGS:
     s = torch.rand(B, cin, device="cuda") + 0.5
     d = torch.rand(B, cout, device="cuda") + 0.5
     flop = 2.0 * B * cout * cin * 9 * H * H
-    mc.WINOGRAD = False
+    mc.WINO_FORCE = "direct"
     t_d = timeit(lambda: mc.modconv_raw(x, w, s, d, mc.PLAIN, 0))
     row = f"{str((B, cin, cout, H)):28s} {t_d:10.1f} {flop / t_d / 1e6:7.1f} | "
-    mc.WINOGRAD, mc.WINO_MIN_TILES = True, 1
     for sk in splits:
-        mc.WINO_SPLITK = sk
+        mc.WINO_FORCE = sk
         t_w = timeit(lambda: mc.modconv_raw(x, w, s, d, mc.PLAIN, 0))
         row += f"{t_w:13.1f} {flop / t_w / 1e6:6.1f} | "
     print(row, flush=True)
