@@ -22,7 +22,8 @@ SOURCES = {
     "fused_bias_act.hip": [],
     "upfirdn2d.hip": [],
     "modconv.hip": [],
-    "winograd.hip": [],
+    # packed f32 VALU (v_pk_*) beside MFMAs costs more than it saves (MI355X_MICROARCH.md): no SLP packing
+    "winograd.hip": ["-fno-slp-vectorize"],
     "rowops.hip": [],
     "lpips.hip": [],
     "geometry.hip": ["-ffp-contract=off"],

@@ -268,7 +268,9 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
             }
         }
         if constexpr (WIDE && SCALE) { rs[0] = rsn[0]; rs[1] = rsn[1]; }
-        __syncthreads();
+        // LDS hand-over only: __syncthreads() would also wait (vmcnt(0)) for the global loads of
+        // tile kt+2 issued a few instructions ago and expose their latency at every K tile
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     int kt = kt_begin;
     for (; kt + 1 < kt_end; kt += 2) {  // unrolled by two: LDS buffer indices are compile-time

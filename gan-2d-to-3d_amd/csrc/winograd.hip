@@ -255,39 +255,90 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
         //   * the fragments of k-step 1 are read under the MFMAs of k-step 0;
         //   * after the hand-over barrier the k-step-0 fragments of tile kt+1 are read under the last 4
         //     MFMAs of k-step 1, so that the matrix pipe does not wait for LDS after the barrier.
+        // Hand-placed schedule: a wave issues in order and a second MFMA waits ~64 cycles for the
+        // matrix pipe, so each of the 32 MFMA gaps of a K tile gets ONE small slice of the other
+        // work (<= ~8 instructions), pinned with sched_barrier(0):
+        //   gaps  0-3   read 2 fragments of k-step 1 each; write the U registers (tile kt+1) to LDS
+        //   gaps  4-7   patch row i: outer columns from the neighbour lanes, style scale; reload U (kt+2)
+        //   gaps  8-11  row transform of patch column j
+        //   gaps 12-15  reload patch row i (kt+2)
+        //   gaps 16-23  column transform of row i (even gap), its 16-byte LDS write (odd gap)
+        //   gaps 24-27  nothing
+        //   barrier (LDS hand-over only: no vmcnt wait)
+        //   gaps 28-31  read the k-step-0 fragments of tile kt+1
         int cur = 0;
         for (int kt = kt_begin; kt < kt_end; kt++, cur ^= 1) {
-            read_frags(cur, 1, fa1, fb1);
-            stage_tile(cur ^ 1);
-            store_u(cur ^ 1);
-            load_u(min(kt + 2, kt_last));
-            load_tile(min(kt + 2, kt_last));
+            const f32x4 *ua = reinterpret_cast<const f32x4 *>(&Us[0][0] + cur * (16 * WKC * WBM)) + aoff;
+            const f32x4 *va = reinterpret_cast<const f32x4 *>(&Vs[0][0] + cur * (16 * WKC * WBT)) + boff;
+            const f32x4 *un = reinterpret_cast<const f32x4 *>(&Us[0][0] + (cur ^ 1) * (16 * WKC * WBM)) + aoff;
+            const f32x4 *vn = reinterpret_cast<const f32x4 *>(&Vs[0][0] + (cur ^ 1) * (16 * WKC * WBT)) + boff;
+            f32x4 *uw = reinterpret_cast<f32x4 *>(&Us[0][0] + (cur ^ 1) * (16 * WKC * WBM)) + tid;
+            f32x4 *vw = reinterpret_cast<f32x4 *>(&Vs[0][0] + (cur ^ 1) * (16 * WKC * WBT)) + kc * WBT + lane;
+            const int kt2 = min(kt + 2, kt_last);
+            const int kill2 = (PARTIAL && kt2 * WKC + kc >= d.Cr) ? OOB : 0;
+            const int so2 = kt2 * WKC * HW * 4, su2 = (mt * d.ktiles + kt2) * WBLOCK * 4;
+            float t[16];
+            f32x4 v4;
     #pragma unroll
-            for (int p = 0; p < 16; p++)
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[p >> 2][p & 3], fb0[p >> 2][p & 3], acc[p], 0, 0, 0);
+            for (int q = 0; q < 32; q++) {
+                if (q == 28) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (q < 16) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[q >> 2][q & 3], fb0[q >> 2][q & 3], acc[q], 0, 0, 0);
+                else acc[q - 16] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[(q - 16) >> 2][q & 3], fb1[(q - 16) >> 2][q & 3], acc[q - 16], 0, 0, 0);
+                if (q < 4) {
+                    fa1[q] = ua[(q * WKC + 2) * WBM];
+                    fb1[q] = va[(q * WKC + 2) * WBT];
+                    uw[q * 256] = ru4[q];
+                } else if (q < 8) {
+                    const int i = q - 4;
+                    if constexpr (FAST) {
+                        const int left = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rd[i * 4 + 2]), 0x138, 0xf, 0xf, false);
+                        const int right = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rd[i * 4 + 1]), 0x130, 0xf, 0xf, false);
+                        rd[i * 4 + 0] = first_col ? 0.0f : __builtin_bit_cast(float, left);
+                        rd[i * 4 + 3] = last_col ? 0.0f : __builtin_bit_cast(float, right);
+                    }
+                    if constexpr (SCALE) {
     #pragma unroll
-            for (int p = 0; p < 12; p++)
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p >> 2][p & 3], fb1[p >> 2][p & 3], acc[p], 0, 0, 0);
+                        for (int j = 0; j < 4; j++) rd[i * 4 + j] *= rs;
+                    }
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ru, offU + i * 4096, su2, 0);
+                    ru4[i] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+                } else if (q < 12) {
+                    const int j = q - 8;
+                    t[0 * 4 + j] = rd[0 * 4 + j] - rd[2 * 4 + j];
+                    t[1 * 4 + j] = rd[1 * 4 + j] + rd[2 * 4 + j];
+                    t[2 * 4 + j] = rd[2 * 4 + j] - rd[1 * 4 + j];
+                    t[3 * 4 + j] = rd[1 * 4 + j] - rd[3 * 4 + j];
+                } else if (q < 16) {
+                    // registers of patch row i are free (row transform done): reload them with tile kt+2
+                    const int i = q - 12;
+                    if constexpr (FAST) {
+                        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rx, offD[i] | kill2, so2, 0);
+                        rd[i * 4 + 1] = __uint_as_float(v.x);
+                        rd[i * 4 + 2] = __uint_as_float(v.y);
+                    } else {
     #pragma unroll
-            for (int g = 0; g < 28; g++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-                if (g < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (fragments of k-step 1)
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // VALU
-                if (g >= 10 && g < 18) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-                if (g < 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                        for (int j = 0; j < 4; j++)
+                            rd[i * 4 + j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, offD[i * 4 + j] | kill2, so2, 0));
+                    }
+                    if (SCALE && q == 15)
+                        rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, offS | kill2, kt2 * WKC * 4, 0));
+                } else if (q < 24) {
+                    const int i = (q - 16) >> 1;
+                    if ((q & 1) == 0) {   // column transform of row i ...
+                        v4[0] = t[i * 4 + 0] - t[i * 4 + 2];
+                        v4[1] = t[i * 4 + 1] + t[i * 4 + 2];
+                        v4[2] = t[i * 4 + 2] - t[i * 4 + 1];
+                        v4[3] = t[i * 4 + 1] - t[i * 4 + 3];
+                    } else {              // ... and its 16-byte LDS write in the next gap
+                        vw[i * WKC * WBT] = v4;
+                    }
+                } else if (q >= 28) {
+                    const int i = q - 28;
+                    fa0[i] = un[(i * WKC) * WBM];
+                    fb0[i] = vn[(i * WKC) * WBT];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // every load issued above (DMA of U, patch of tile kt+2) has had the MFMA phase to land
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            read_frags(cur ^ 1, 0, fa0, fb0);
-    #pragma unroll
-            for (int p = 12; p < 16; p++)
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[p >> 2][p & 3], fb1[p >> 2][p & 3], acc[p], 0, 0, 0);
-    #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);      // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);      // DS read (k-step-0 fragments of tile kt+1)
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- epilogue: output transform A^T M A in registers, scale / bias / activation, store.
