@@ -68,7 +68,7 @@ struct WinoDesc {
 // this kernel: the matrix work per loaded byte is 2.25x smaller than in the direct GEMM).
 template <bool SCALE, bool PARTIAL, bool FAST>
 __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
-    __shared__ __attribute__((aligned(16))) float Us[2][16 * WKC * WBM];
+    __shared__ __attribute__((aligned(16))) float Us[3][16 * WKC * WBM];   // ring of 3: DMA runs 2 tiles ahead
     __shared__ __attribute__((aligned(16))) float Vs[2][16 * WKC * WBT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lk = lane >> 5;
@@ -95,7 +95,6 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
     constexpr int OOB = 0x7fffffff;
 
     const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, d.B * d.Cr * HW * 4, 0x00020000);
-    const auto ru = __builtin_amdgcn_make_buffer_rsrc((void *)d.U, 0, tiles_m * d.ktiles * WBLOCK * 4, 0x00020000);
     const auto rsc = __builtin_amdgcn_make_buffer_rsrc((void *)(SCALE ? d.in_scale : d.x), 0,
                                                        SCALE ? d.B * d.Cr * 4 : 4, 0x00020000);
 
@@ -136,35 +135,18 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
             }
             if (valid) offS = (b * d.Cr + kc) * 4;
         }
-        // U block of K tile kt -> LDS buffer `buf` by direct DMA: 16 wave-instructions of 1 KB, 4 per wave
+        // U block of K tile kt -> LDS buffer `buf` by direct DMA (global_load_lds_dwordx4: no registers,
+        // no VGPR->LDS transfer): 16 wave-instructions of 1 KB, chunk e * 4 + wave for e = 0..3
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         const char *ubase = reinterpret_cast<const char *>(d.U) + (size_t)mt * d.ktiles * WBLOCK * 4 + lane * 16;
-        auto dma_u = [&](int kt, int buf) {
-            const char *src = ubase + (size_t)kt * WBLOCK * 4;
-    #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int chunk = e * 4 + wave;   // 1 KB chunk of the 16 KB block
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + chunk * 1024),
-                    (__attribute__((address_space(3))) void *)(&Us[0][0] + buf * (16 * WKC * WBM) + chunk * 256), 16, 0, 0);
-            }
+        auto dma_u = [&](int kt, int buf, const int e) {
+            const int chunk = e * 4 + wave_u;   // 1 KB chunk of the 16 KB block
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(ubase + (size_t)kt * WBLOCK * 4 + chunk * 1024),
+                (__attribute__((address_space(3))) void *)(&Us[0][0] + buf * (16 * WKC * WBM) + chunk * 256), 16, 0, 0);
         };
 
         float rd[16], rs = 1.0f;    // FAST: rd[i*4+1], rd[i*4+2] hold the loaded middle columns
-        f32x4 ru4[4];
-        const int offU = tid * 16;
-        auto load_u = [&](int kt) {
-            const int su = (mt * d.ktiles + kt) * WBLOCK * 4;
-    #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ru, offU + e * 4096, su, 0);
-                ru4[e] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-            }
-        };
-        auto store_u = [&](int buf) {
-            f32x4 *ub = reinterpret_cast<f32x4 *>(&Us[0][0] + buf * (16 * WKC * WBM)) + tid;
-    #pragma unroll
-            for (int e = 0; e < 4; e++) ub[e * 256] = ru4[e];
-        };
         auto load_tile = [&](int kt) {
             // surplus channels of the last tile: an out-of-range offset makes the hardware return 0
             const int kill = (PARTIAL && kt * WKC + kc >= d.Cr) ? OOB : 0;  // wave-uniform
@@ -237,13 +219,14 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
             }
         };
 
-        load_u(kt_begin);
+    #pragma unroll
+        for (int e = 0; e < 4; e++) dma_u(kt_begin, 0, e);
+    #pragma unroll
+        for (int e = 0; e < 4; e++) dma_u(min(kt_begin + 1, kt_last), 1, e);
         load_tile(kt_begin);
         stage_tile(0);
-        store_u(0);
-        load_u(min(kt_begin + 1, kt_last));
         load_tile(min(kt_begin + 1, kt_last));
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         read_frags(0, 0, fa0, fb0);
 
         // Software pipeline of one K tile (ONE loop body: the 256 accumulator registers must not be
@@ -258,8 +241,10 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
         // Hand-placed schedule: a wave issues in order and a second MFMA waits ~64 cycles for the
         // matrix pipe, so each of the 32 MFMA gaps of a K tile gets ONE small slice of the other
         // work (<= ~8 instructions), pinned with sched_barrier(0):
-        //   gaps  0-3   read 2 fragments of k-step 1 each; write the U registers (tile kt+1) to LDS
-        //   gaps  4-7   patch row i: outer columns from the neighbour lanes, style scale; reload U (kt+2)
+        //   gaps  0-3   read 2 fragments of k-step 1 each
+        //   gaps  4-7   patch row i: outer columns from the neighbour lanes, style scale; one DMA chunk of
+        //               the U block of tile kt+2 (ring of 3 LDS buffers: everything a wave loads in
+        //               iteration kt is first needed in iteration kt+1, a whole MFMA phase later)
         //   gaps  8-11  row transform of patch column j
         //   gaps 12-15  reload patch row i (kt+2)
         //   gaps 16-23  column transform of row i (even gap), its 16-byte LDS write (odd gap)
@@ -267,16 +252,16 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
         //   barrier (LDS hand-over only: no vmcnt wait)
         //   gaps 28-31  read the k-step-0 fragments of tile kt+1
         int cur = 0;
+        int ub0 = 0, ub1 = 1, ub2 = 2;   // U ring: tile kt, kt+1, kt+2
         for (int kt = kt_begin; kt < kt_end; kt++, cur ^= 1) {
-            const f32x4 *ua = reinterpret_cast<const f32x4 *>(&Us[0][0] + cur * (16 * WKC * WBM)) + aoff;
+            const f32x4 *ua = reinterpret_cast<const f32x4 *>(&Us[0][0] + ub0 * (16 * WKC * WBM)) + aoff;
             const f32x4 *va = reinterpret_cast<const f32x4 *>(&Vs[0][0] + cur * (16 * WKC * WBT)) + boff;
-            const f32x4 *un = reinterpret_cast<const f32x4 *>(&Us[0][0] + (cur ^ 1) * (16 * WKC * WBM)) + aoff;
+            const f32x4 *un = reinterpret_cast<const f32x4 *>(&Us[0][0] + ub1 * (16 * WKC * WBM)) + aoff;
             const f32x4 *vn = reinterpret_cast<const f32x4 *>(&Vs[0][0] + (cur ^ 1) * (16 * WKC * WBT)) + boff;
-            f32x4 *uw = reinterpret_cast<f32x4 *>(&Us[0][0] + (cur ^ 1) * (16 * WKC * WBM)) + tid;
             f32x4 *vw = reinterpret_cast<f32x4 *>(&Vs[0][0] + (cur ^ 1) * (16 * WKC * WBT)) + kc * WBT + lane;
             const int kt2 = min(kt + 2, kt_last);
             const int kill2 = (PARTIAL && kt2 * WKC + kc >= d.Cr) ? OOB : 0;
-            const int so2 = kt2 * WKC * HW * 4, su2 = (mt * d.ktiles + kt2) * WBLOCK * 4;
+            const int so2 = kt2 * WKC * HW * 4;
             float t[16];
             f32x4 v4;
     #pragma unroll
@@ -287,7 +272,6 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
                 if (q < 4) {
                     fa1[q] = ua[(q * WKC + 2) * WBM];
                     fb1[q] = va[(q * WKC + 2) * WBT];
-                    uw[q * 256] = ru4[q];
                 } else if (q < 8) {
                     const int i = q - 4;
                     if constexpr (FAST) {
@@ -300,8 +284,7 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
     #pragma unroll
                         for (int j = 0; j < 4; j++) rd[i * 4 + j] *= rs;
                     }
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ru, offU + i * 4096, su2, 0);
-                    ru4[i] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+                    dma_u(kt2, ub2, i);   // U of tile kt+2 -> the ring slot that held tile kt-1
                 } else if (q < 12) {
                     const int j = q - 8;
                     t[0 * 4 + j] = rd[0 * 4 + j] - rd[2 * 4 + j];
@@ -339,6 +322,10 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            const int ufree = ub0;
+            ub0 = ub1;
+            ub1 = ub2;
+            ub2 = ufree;
         }
 
         // ---- epilogue: output transform A^T M A in registers, scale / bias / activation, store.
