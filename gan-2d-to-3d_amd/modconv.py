@@ -33,6 +33,7 @@ class profiled:
     def __init__(self, flop, nbytes, mfma_flop=None):
         self.rec = PROFILE
         self.flop, self.nbytes = flop, nbytes
+        self.kernel = "direct" if mfma_flop is None else "winograd"
         self.mfma_flop = flop if mfma_flop is None else mfma_flop
 
     def __enter__(self):
@@ -44,7 +45,7 @@ class profiled:
     def __exit__(self, *exc):
         if self.rec is not None:
             self.e1.record()
-            self.rec.append((self.flop, self.e0, self.e1, self.nbytes, self.mfma_flop))
+            self.rec.append((self.flop, self.e0, self.e1, self.nbytes, self.mfma_flop, self.kernel))
         return False
 
 
