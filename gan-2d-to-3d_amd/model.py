@@ -278,7 +278,8 @@ class GAN2Shape(nn.Module):
 
         with torch.no_grad():
             pseudo_im, mask = self.sample_pseudo_imgs(n_proj_samples, normal, light_a, light_b,
-                                                      albedo, depth, canon_mask)
+                                                      albedo, depth, canon_mask,
+                                                      _draws=kwargs.get('_draws'))
             gan_im = None
             if self.relative_encoding:
                 gan_im, _ = self.generator([latent], input_is_w=True,
@@ -311,19 +312,27 @@ class GAN2Shape(nn.Module):
         offset = self.generator.style_forward(hidden, skip=8 - F1_d) - center_w
         return offset, latent + offset
 
-    def sample_pseudo_imgs(self, n_images, normal, light_a, light_b, albedo, depth, canon_mask=None):
-        """model.py:291-328: random relighting (3 uniform draws) + n random views."""
+    def sample_pseudo_imgs(self, n_images, normal, light_a, light_b, albedo, depth, canon_mask=None,
+                           _draws=None):
+        """model.py:291-328: random relighting (3 uniform draws) + n random views.
+        `_draws` = (light dxy [n,2], diffuse rand [n,1,1,1], views [n,6]) replaces the three random
+        draws (parity tests feed the draws of a recorded reference run; the device generator cannot
+        reproduce a CPU generator's stream)."""
         h, w = self.image_size, self.image_size
         dev = self.device
         x_min, x_max, y_min, y_max, diffuse_min, diffuse_max, alpha = self.rand_light
         rand_light_dxy = torch.empty(n_images, 2, device=dev)
         rand_light_dxy[:, 0].uniform_(x_min, x_max)
         rand_light_dxy[:, 1].uniform_(y_min, y_max)
+        if _draws is not None:
+            rand_light_dxy = _draws[0].to(dev)
         rand_light_d = torch.cat([rand_light_dxy, torch.ones(n_images, 1, device=dev)], 1)
         rand_light_d = rand_light_d / ((rand_light_d ** 2).sum(1, keepdim=True)) ** 0.5
         rand_diffuse_shading = (normal[0, None] * rand_light_d.view(-1, 1, 1, 3)).sum(3)\
             .clamp(min=0).unsqueeze(1)
         rand = torch.empty(n_images, 1, 1, 1, device=dev).uniform_(diffuse_min, diffuse_max)
+        if _draws is not None:
+            rand = _draws[1].to(dev)
         rand_diffuse = (light_b[0, None].view(-1, 1, 1, 1) + rand) * rand_diffuse_shading
         rand_shading = light_a[0, None].view(-1, 1, 1, 1) + alpha * rand + rand_diffuse
         rand_light_im = (albedo[0, None] / 2 + 0.5) * rand_shading * 2 - 1
@@ -335,6 +344,8 @@ class GAN2Shape(nn.Module):
             mask = torch.ones(n_images, 3, h, w, device=dev)
 
         rand_views = self.view_light_sampler.sample(n_images, 'view')
+        if _draws is not None:
+            rand_views = _draws[2].to(dev)
         rand_views_trans = self.get_view_transformation(rand_views)
         pseudo_im, mask = self.renderer.render_given_view(rand_light_im, depth.expand(n_images, h, w),
                                                           view=rand_views_trans, mask=mask,

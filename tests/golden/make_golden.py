@@ -337,6 +337,171 @@ def model_golden():
     np.savez_compressed(os.path.join(OUT, "model.npz"), **out)
 
 
+def _oracle_neural_renderer():
+    """A `neural_renderer` module for the reference's Renderer to bind (renderer.py:6,47-54,120): its
+    render_depth is THIS repo's C oracle (oracle/raster_body.inc — SURVEY.md Appendix A restated;
+    PARITY UNPINNED, the real package is un-vendored), forward and backward.  Everything around it
+    — the three step functions, shading, sampling, losses, the trained nets, G and D — is the
+    reference's own code, so the step-level fixtures pin that code conditional on the rasterizer."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import capi
+
+    class _RenderDepth(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, verts, faces, S, K):
+            v = verts.detach().numpy().astype(np.float32)
+            f = faces[0].numpy().astype(np.int32)
+            ref = capi.render_depth(v, f, S, K)
+            ctx.save_for_backward(verts)
+            ctx.aux = (f, S, K, ref["face_idx"], ref["bary"])
+            return torch.from_numpy(ref["depth"])
+
+        @staticmethod
+        def backward(ctx, g):
+            (verts,) = ctx.saved_tensors
+            f, S, K, fidx, bary = ctx.aux
+            gv = capi.render_depth_bwd(verts.detach().numpy().astype(np.float32), f,
+                                       g.contiguous().numpy().astype(np.float32), fidx, bary, S, K)
+            return torch.from_numpy(gv), None, None, None
+
+    class Renderer:
+        def __init__(self, K=None, image_size=256, **kwargs):
+            self.K, self.image_size = K, image_size
+
+        def render_depth(self, vertices, faces):
+            return _RenderDepth.apply(vertices, faces, self.image_size, np_(self.K)[0].astype(np.float32))
+
+    mod = types.ModuleType("neural_renderer")
+    mod.Renderer = Renderer
+    return mod
+
+
+class _torch12_grid_sample:
+    """The reference targets torch 1.2, whose grid_sample is what torch >= 1.3 calls
+    align_corners=True; its call sites (model.py:151,270, renderer.py:261,263)
+    pass no flag."""
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.F, self.orig = F, F.grid_sample
+        orig = self.orig
+        F.grid_sample = lambda *a, **k: orig(*a, **{"align_corners": True, **k})
+
+    def __exit__(self, *exc):
+        self.F.grid_sample = self.orig
+
+
+def steps_golden():
+    """The three training steps of the REFERENCE's GAN2Shape (model.py:95-328) run on the CPU: face
+    config at 128x128, n_proj = 2, seeded weights (regenerated by the test: tests/model_cases.py),
+    a stand-in perceptual loss, the oracle rasterizer behind the neural_renderer boundary.
+    Stored: inputs, the random draws of step 2, every `collected` hand-off, the losses and
+    per-net gradient norms."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(OUT))
+    import model_cases as mc
+    sys.modules["neural_renderer"] = _oracle_neural_renderer()
+    for name in [m for m in sys.modules if m.startswith("GAN2Shape.renderer")]:
+        del sys.modules[name]       # re-import against the behavioural stand-in
+    ref_model, ref_losses, _ = _import_reference_model()
+    import importlib
+    importlib.reload(sys.modules["GAN2Shape.renderer.renderer"]) if "GAN2Shape.renderer.renderer" in sys.modules else None
+    importlib.reload(ref_model)
+    sys.path.insert(0, SG2)
+    import model as sg2
+    from GAN2Shape import networks as ref_nets
+    cfg = mc.STEP_CFG
+    S, n = cfg["image_size"], cfg["n_proj"]
+    out = {}
+    with _cuda_is_identity(), _torch12_grid_sample():
+        M = object.__new__(ref_model.GAN2Shape)
+        torch.nn.Module.__init__(M)
+        M.z_dim, M.debug, M.image_size, M.collected = cfg["z_dim"], False, S, None
+        M.generator = sg2.Generator(cfg["gan_size"], cfg["z_dim"], 8, channel_multiplier=1).eval()
+        M.discriminator = sg2.Discriminator(cfg["gan_size"], channel_multiplier=1).eval()
+        mc.prepare_generator(M.generator, cfg["seeds"]["G"], fill_deterministic)
+        fill_deterministic(M.discriminator, cfg["seeds"]["D"])
+        for name, cls in (("lighting", "LightingNet"), ("viewpoint", "ViewpointNet"), ("depth", "DepthNet"),
+                          ("albedo", "AlbedoNet"), ("offset_encoder", "OffsetEncoder")):
+            net = getattr(ref_nets, cls)(S)
+            mc.fill_scaled(net, cfg["seeds"][name])
+            setattr(M, f"{name}_net", net)
+        M.max_depth, M.min_depth = 1.1, 0.9
+        M.border_depth = 0.7 * M.max_depth + 0.3 * M.min_depth
+        M.lam_perc, M.lam_smooth, M.lam_regular = 1, 0.01, 0.01
+        M.xyz_rotation_range, M.xy_translation_range, M.z_translation_range = 60, 0.1, 0.1
+        M.use_mask, M.relative_encoding = True, False
+        M.rand_light = [-1, 1, -0.2, 0.8, -0.1, 0.6, -0.6]
+        M.truncation, M.mean_latent = 1, None
+        from GAN2Shape.renderer import Renderer as RefRenderer
+        M.renderer = RefRenderer({"rot_center_depth": 1.0, "fov": 10, "tex_cube_size": 2}, S, M.min_depth, M.max_depth)
+        g = torch.Generator().manual_seed(7)
+        vm, lm = 0.05 * torch.randn(6, generator=g), 0.05 * torch.randn(4, generator=g)
+        vc = torch.diag(torch.tensor([.05, .15, .03, .05, .05, .05]) ** 2)
+        lc = 0.01 * torch.eye(4)
+        with tempfile.TemporaryDirectory() as tmp:
+            torch.save({"mean": vm, "cov": vc}, os.path.join(tmp, "v.pth"))
+            torch.save({"mean": lm, "cov": lc}, os.path.join(tmp, "l.pth"))
+            M.view_light_sampler = ref_model.ViewLightSampler(os.path.join(tmp, "v.pth"), os.path.join(tmp, "l.pth"), 1)
+        for k_, v in dict(vm=vm, vc=vc, lm=lm, lc=lc).items():
+            out[f"vls.{k_}"] = np_(v)
+        M.smooth_loss, M.photometric_loss = ref_losses.SmoothLoss(), ref_losses.PhotometricLoss()
+        M.discriminator_loss = ref_losses.DiscriminatorLoss()
+        M.perceptual_loss = mc.fake_perceptual
+
+        image = torch.tanh(torch.nn.functional.interpolate(torch.randn(1, 3, 32, 32, generator=g), scale_factor=4,
+                                                           mode="bilinear"))
+        with torch.no_grad():
+            latent = M.generator.style_forward(torch.randn(1, cfg["z_dim"], generator=g))
+        out["image"], out["latent"] = np_(image), np_(latent)
+        nets = ("lighting", "viewpoint", "depth", "albedo", "offset_encoder")
+
+        def grad_norms(tag):
+            for name in nets:
+                ps = [p.grad for p in getattr(M, f"{name}_net").parameters() if p.grad is not None]
+                out[f"{tag}.gnorm.{name}"] = np.array(float(sum((q.double() ** 2).sum() for q in ps)) ** 0.5 if ps else 0.0)
+            for p in M.parameters():
+                p.grad = None
+
+        # ---- step 1 (model.py:95-173)
+        loss1, c1 = M.forward_step1(image, latent, None)
+        loss1.backward()
+        grad_norms("s1")
+        out["s1.loss"] = np_(loss1)
+        for k_, v in zip(("normal", "light_a", "light_b", "albedo", "depth"), c1[:5]):
+            out[f"s1.{k_}"] = np_(v)
+        recon_im, recon_depth = M.forward_step1(image, None, None, eval=True)
+        out["s1.recon_im"], out["s1.recon_depth"] = np_(recon_im), np_(recon_depth)
+
+        # ---- step 2 (model.py:175-223, 291-328); the draws are replayed after the same seed
+        c1d = tuple(t.detach() if torch.is_tensor(t) else t for t in c1)
+        torch.manual_seed(11)
+        dxy = torch.FloatTensor(n, 2)
+        dxy[:, 0].uniform_(M.rand_light[0], M.rand_light[1])
+        dxy[:, 1].uniform_(M.rand_light[2], M.rand_light[3])
+        rnd = torch.FloatTensor(n, 1, 1, 1).uniform_(M.rand_light[4], M.rand_light[5])
+        views = M.view_light_sampler.sample(n, "view")
+        out["s2.draw.dxy"], out["s2.draw.rand"], out["s2.draw.views"] = np_(dxy), np_(rnd), np_(views)
+        torch.manual_seed(11)
+        with torch.no_grad():
+            pseudo_im, pmask = M.sample_pseudo_imgs(n, *c1d[:5], c1d[5])
+        out["s2.pseudo_im"], out["s2.pseudo_mask"] = np_(pseudo_im), np_(pmask)
+        torch.manual_seed(11)
+        loss2, c2 = M.forward_step2(image, latent, c1d, n_proj_samples=n)
+        loss2.backward()
+        grad_norms("s2")
+        out["s2.loss"] = np_(loss2)
+        out["s2.loss_l1"], out["s2.loss_rec"], out["s2.loss_latent_norm"] = np_(M.loss_l1), np_(M.loss_rec), np_(M.loss_latent_norm)
+        out["s2.projected"], out["s2.mask"] = np_(c2[0]), np_(c2[1])
+
+        # ---- step 3 (model.py:225-280)
+        loss3, _ = M.forward_step3(image, latent, c2)
+        loss3.backward()
+        grad_norms("s3")
+        out["s3.loss"] = np_(loss3)
+    np.savez_compressed(os.path.join(OUT, "steps.npz"), **{k: (v.astype(np.float32) if v.dtype == np.float64 and v.ndim else v)
+                                                            for k, v in out.items()})
+
+
 def fill_deterministic(module, seed):
     """Overwrite every parameter and buffer with seeded values, visiting the state dict in sorted
     key order — the test does the same on the build's state-dict-compatible module, so the weights
@@ -436,6 +601,7 @@ if __name__ == "__main__":
     misc_golden()
     gan_golden()
     model_golden()
+    steps_golden()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -70,3 +70,46 @@ def bare_model(device="cpu", fused=True):
     m.depth_net = fake_depth_net
     m.renderer = types.SimpleNamespace(fused=fused)
     return m
+
+
+def fill_scaled(module, seed, gain=1.0):
+    """Seeded, variance-preserving fill of a trained net (sorted state-dict order, like
+    make_golden.fill_deterministic): conv / linear weights ~ N(0, gain^2 / fan_in), norm scales
+    1 + 0.1 N, biases 0.1 N — keeps the activations of the 7-17-layer nets in range."""
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k in sorted(sd.keys()):
+            t = sd[k]
+            if not t.is_floating_point():
+                continue
+            v = torch.randn(t.shape, generator=g)
+            if t.dim() > 1:
+                fan_in = t[0].numel()
+                v = v * (gain / fan_in ** 0.5)
+            elif k.endswith("weight"):
+                v = 1 + 0.1 * v
+            else:
+                v = 0.1 * v
+            t.copy_(v)
+
+
+def fake_perceptual(pred, target):
+    """Stand-in for LPIPS (the reference's lpips package needs torchvision's pretrained VGG16):
+    same call shape PerceptualLoss(pred, target) -> (B, 1, 1, 1)."""
+    d = F.avg_pool2d(pred, 4) - F.avg_pool2d(target, 4)
+    return (d ** 2).mean((1, 2, 3)).view(-1, 1, 1, 1) + (d.abs() ** 1.5).mean((1, 2, 3)).view(-1, 1, 1, 1)
+
+
+STEP_CFG = dict(image_size=128, gan_size=128, z_dim=512, channel_multiplier=1, n_proj=2,
+                seeds=dict(G=41, D=42, lighting=43, viewpoint=44, depth=45, albedo=46, offset_encoder=47))
+
+
+def prepare_generator(G, seed, fill_deterministic):
+    """fill_deterministic leaves the mapping network's weights at N(0, 1) although EqualLinear keeps
+    them at N(0, 1) / lr_mul (lr_mul = 0.01): restore that scale so that latent offsets matter."""
+    fill_deterministic(G, seed)
+    with torch.no_grad():
+        for layer in G.style:
+            if hasattr(layer, "weight"):
+                layer.weight.mul_(100.0)
