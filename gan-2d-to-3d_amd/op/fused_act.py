@@ -1,6 +1,8 @@
 """`FusedLeakyReLU`, `fused_leaky_relu` — the Python op API of
 GAN2Shape/stylegan2/stylegan2-pytorch/op/fused_act.py:74-92 — and `fused_noise_bias_act`, on the
-`fused` plugin (libg2s.so).  No native fallback.
+`fused` plugin (libg2s.so).  CUDA tensors always take the plugin (no fallback: a missing library
+raises); CPU tensors get the reference's plain-PyTorch answer (op/cpu_tensors.py), as in the
+reference's own `op` package.
 
 Autograd structure (own): the activation's derivative  g -> g * scale * (out > 0 ? 1 : slope)  is
 linear in g, so ONE function (`_SlopeGate`) serves as the backward of every fused activation and
@@ -53,6 +55,9 @@ class _BiasLeakyReLU(Function):
 
 def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
     """sqrt(2) * leaky_relu(input + bias[c], 0.2) by default (fused_act.py:86-92)."""
+    if not input.is_cuda:      # the reference's device split (fused_act.py:87)
+        from . import cpu_tensors
+        return cpu_tensors.fused_leaky_relu(input, bias, negative_slope, scale)
     _lib.require_cuda(input, bias)
     return _BiasLeakyReLU.apply(input, bias, negative_slope, scale)
 

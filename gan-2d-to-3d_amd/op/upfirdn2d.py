@@ -1,6 +1,7 @@
 """`upfirdn2d(input, kernel, up, down, pad)` — the Python op API of
 GAN2Shape/stylegan2/stylegan2-pytorch/op/upfirdn2d.py:144-154 — on the `upfirdn2d_op` plugin
-(libg2s.so).  No native fallback.
+(libg2s.so).  CUDA tensors always take the plugin (no fallback: a missing library raises); CPU
+tensors get the reference's plain-PyTorch answer (op/cpu_tensors.py), as in the reference's `op`.
 
 Autograd structure (own): the adjoint of "upsample by u, pad, FIR with k, downsample by d" is the
 same operation with u and d swapped, the flipped kernel and complementary padding, so a single
@@ -59,5 +60,8 @@ class _Resample(Function):
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     """Upsample by `up` (zero insertion), pad by `pad` = (before, after) on both axes (negative =
     crop), filter with the 2-D FIR `kernel`, keep every `down`-th sample."""
+    if not input.is_cuda:      # the reference's device split (upfirdn2d.py:145)
+        from . import cpu_tensors
+        return cpu_tensors.upfirdn2d(input, kernel, up, down, pad)
     _lib.require_cuda(input, kernel)
     return _Resample.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]), None)

@@ -502,6 +502,50 @@ def steps_golden():
                                                             for k, v in out.items()})
 
 
+def trainer_golden():
+    """The reference's Trainer.fit (GAN2Shape/trainer.py:13-171) driving a toy model
+    (tests/model_cases.py:ToyStepModel) on the CPU: the order of calls, every loss, the final
+    parameters.  `plotting` (matplotlib / plotly) is an import-only placeholder and the
+    PriorGenerator (needs parsing-net checkpoints) returns a fixed map."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import model_cases as mc
+    _import_reference_model()
+    plotting = types.ModuleType("plotting")
+    plotting.plot_predicted_depth_map = plotting.plot_reconstructions = lambda *a, **k: None
+    sys.modules["plotting"] = plotting
+    import GAN2Shape.trainer as ref_trainer
+
+    class FixedPrior:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, image, *a, **k):
+            return torch.full((1, 8, 8), 0.97)
+    ref_trainer.PriorGenerator = FixedPrior
+    ref_trainer.tqdm = lambda it, *a, **k: _Quiet(it)
+    with _cuda_is_identity():
+        t = ref_trainer.Trainer(mc.ToyStepModel, dict(mc.TOY_CFG))
+        t.fit(mc.toy_dataset(), stages=mc.TOY_STAGES)
+    out = {"log": np.array(t.model.log, np.float64),
+           "params": np_(torch.cat([p.reshape(-1) for p in t.model.parameters()]))}
+    np.savez_compressed(os.path.join(OUT, "trainer.npz"), **out)
+
+
+class _Quiet:
+    """tqdm stand-in: iterable with the two methods trainer.py calls on it."""
+    def __init__(self, it):
+        self.it = it
+
+    def __iter__(self):
+        return iter(self.it)
+
+    def __len__(self):
+        return len(self.it)
+
+    def set_description(self, *a, **k):
+        pass
+
+
 def fill_deterministic(module, seed):
     """Overwrite every parameter and buffer with seeded values, visiting the state dict in sorted
     key order — the test does the same on the build's state-dict-compatible module, so the weights
@@ -602,6 +646,7 @@ if __name__ == "__main__":
     gan_golden()
     model_golden()
     steps_golden()
+    trainer_golden()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -113,3 +113,62 @@ def prepare_generator(G, seed, fill_deterministic):
         for layer in G.style:
             if hasattr(layer, "weight"):
                 layer.weight.mul_(100.0)
+
+
+class ToyStepModel(torch.nn.Module):
+    """Tiny CPU model with the step API the trainers drive (trainer.py:23,40-48,103-104,147): five
+    linear `*_net`s, each step's loss depends on the `collected` handed over from the previous step
+    kind, every call is logged.  Same class for the reference's Trainer and this package's."""
+
+    def __init__(self, config, debug=False, device="cpu"):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        for name in ("albedo", "offset_encoder", "lighting", "viewpoint", "depth"):
+            lin = torch.nn.Linear(12, 4)
+            with torch.no_grad():
+                lin.weight.copy_(torch.randn(4, 12, generator=g) * 0.3)
+                lin.bias.copy_(torch.randn(4, generator=g) * 0.1)
+            setattr(self, f"{name}_net", lin)
+        self.batch_mean = None
+        self.log = []   # (call kind, loss)
+
+    @staticmethod
+    def _feat(images):
+        return images.reshape(len(images), -1)[:, :12]
+
+    def depth_net_forward(self, inputs, prior):
+        d = self.depth_net(self._feat(inputs))
+        loss = ((d - d.mean()) ** 2).mean() + (d.mean() - prior.mean()) ** 2
+        self.log.append((0, float(loss.detach())))
+        return loss, d
+
+    def forward_step1(self, images, latents, collected, **kw):
+        assert collected is None
+        a = self.albedo_net(self._feat(images))
+        d = self.depth_net(self._feat(images)).detach()
+        loss = ((a - d) ** 2).mean() + 0.1 * (a * latents[:, :4]).mean()
+        self.log.append((1, float(loss.detach())))
+        return loss, (a.detach(), d)
+
+    def forward_step2(self, image, latent, collected, n_proj_samples=8, **kw):
+        a, d = collected
+        e = self.offset_encoder_net(self._feat(image))
+        loss = ((e - a) ** 2).mean() + 0.01 * n_proj_samples * (e * d).mean()
+        self.log.append((2, float(loss.detach())))
+        return loss, (e.detach(),)
+
+    def forward_step3(self, image, latent, collected, **kw):
+        (e,) = collected
+        out = sum(getattr(self, f"{n}_net")(self._feat(image)) for n in ("lighting", "viewpoint", "depth", "albedo"))
+        loss = ((out - e) ** 2).mean()
+        self.log.append((3, float(loss.detach())))
+        return loss, None
+
+
+def toy_dataset(n=2):
+    g = torch.Generator().manual_seed(9)
+    return [(torch.randn(3, 8, 8, generator=g), torch.randn(8, generator=g), i) for i in range(n)]
+
+
+TOY_STAGES = [{'step1': 2, 'step2': 1, 'step3': 2}, {'step1': 1, 'step2': 3, 'step3': 1}]
+TOY_CFG = {"image_size": 8, "category": "face", "n_proj_samples": 3, "n_epochs_prior": 2, "prior_name": "ellipsoid"}

@@ -56,12 +56,37 @@ def test_argument_validation_without_gpu():
         lib.check(rc)
 
 
-def test_no_cpu_fallback():
+def test_gpu_path_has_no_fallback_cpu_tensors_take_the_reference_split(golden, monkeypatch):
+    """The reference's `op` package answers CPU tensors with plain PyTorch and CUDA tensors with the
+    native module (op/fused_act.py:87, op/upfirdn2d.py:145).  Same split here: CPU tensors reproduce
+    the reference goldens; the native plugins refuse CPU tensors like the reference's CHECK_CUDA; and
+    nothing stands in for a missing libg2s.so."""
     from gan2shape_amd.op import fused_leaky_relu, upfirdn2d
+    from gan2shape_amd.plugins import fused, upfirdn2d_op
+    g = golden("ops")
+    for name in ("4d", "2d"):
+        x = T(g[f"fused.{name}.x"]).requires_grad_(True)
+        b = T(g[f"fused.{name}.b"]).requires_grad_(True)
+        y = fused_leaky_relu(x, b)
+        gx, gb = torch.autograd.grad(y, (x, b), T(g[f"fused.{name}.gy"]))
+        np.testing.assert_allclose(y.detach().numpy(), g[f"fused.{name}.y"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(gx.numpy(), g[f"fused.{name}.gx"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(gb.numpy(), g[f"fused.{name}.gb"], rtol=1e-5, atol=1e-6)
+    for name in ("blur_up", "rgb_up", "d_blur3", "d_blur1", "down2", "crop"):
+        up, down, p0, p1 = (int(v) for v in g[f"upfirdn2d.{name}.args"])
+        x = T(g[f"upfirdn2d.{name}.x"]).requires_grad_(True)
+        y = upfirdn2d(x, T(g[f"upfirdn2d.{name}.k"]), up=up, down=down, pad=(p0, p1))
+        (gx,) = torch.autograd.grad(y, x, T(g[f"upfirdn2d.{name}.gy"]))
+        np.testing.assert_allclose(y.detach().numpy(), g[f"upfirdn2d.{name}.y"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(gx.numpy(), g[f"upfirdn2d.{name}.gx"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):      # the native modules themselves: CUDA tensors only
+        fused.fused_bias_act(torch.randn(2, 3), torch.zeros(3), torch.empty(0), 3, 0, 0.2, 1.0)
     with pytest.raises(RuntimeError):
-        fused_leaky_relu(torch.randn(2, 3), torch.zeros(3))
-    with pytest.raises(RuntimeError):
-        upfirdn2d(torch.randn(1, 1, 4, 4), torch.ones(4, 4))
+        upfirdn2d_op.upfirdn2d(torch.randn(1, 4, 4, 1), torch.ones(4, 4), 1, 1, 1, 1, 0, 0, 0, 0)
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", os.path.join(ROOT, "no_such_dir", "libg2s.so"))
+    with pytest.raises(lib.G2SError):      # a missing library raises: nothing stands in for it
+        lib.load()
 
 
 def test_product_never_imports_the_oracle():
@@ -237,6 +262,30 @@ def test_priors_golden(golden):
             source = fm.confidence_mask if "confidence" in name else fm
             p = priors.PriorGenerator(size, "face", name, masking_model=source)(img, device="cpu")
             np.testing.assert_allclose(p.numpy(), g[key], rtol=2e-6, atol=1e-6, err_msg=key)
+
+
+# ----------------------------------------------------------------------------- trainer loop (reference fixture)
+def test_trainer_fit_follows_reference_loop(golden):
+    """Trainer.fit against the reference's own Trainer.fit (GAN2Shape/trainer.py:57-128,130-171)
+    driving the same toy model on the CPU (tests/golden/trainer.npz): identical order of calls
+    (prior pre-training, stages x steps x iterations, the `collected` hand-off), identical losses
+    and final parameters — three persistent Adams, a fresh one per image for the prior."""
+    from gan2shape_amd.trainer import Trainer
+    from model_cases import TOY_CFG, TOY_STAGES, ToyStepModel, toy_dataset
+    g = golden("trainer")
+
+    class FixedPrior:
+        def __call__(self, image, device="cpu"):
+            return torch.full((1, 8, 8), 0.97)
+    t = Trainer(ToyStepModel, dict(TOY_CFG), device="cpu")
+    t.prior_generator = FixedPrior()
+    n = t.fit(toy_dataset(), stages=TOY_STAGES)
+    log = np.array(t.model.log, np.float64)
+    assert n == int((g["log"][:, 0] > 0).sum())
+    np.testing.assert_array_equal(log[:, 0], g["log"][:, 0])          # call order
+    np.testing.assert_allclose(log[:, 1], g["log"][:, 1], rtol=1e-6)   # every loss
+    params = torch.cat([p.reshape(-1) for p in t.model.parameters()]).detach().numpy()
+    np.testing.assert_allclose(params, g["params"], rtol=1e-6, atol=1e-7)
 
 
 # ----------------------------------------------------------------------------- reference (live)
