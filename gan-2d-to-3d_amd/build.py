@@ -19,6 +19,7 @@ SOURCES = {
     # file: extra flags
     "api.hip": [],
     "raster.hip": ["-ffp-contract=off"],  # bit-parity with the oracle's unfused arithmetic
+    "raster_rgb.hip": ["-ffp-contract=off"],
     "fused_bias_act.hip": [],
     "upfirdn2d.hip": [],
     "modconv.hip": [],

@@ -5,8 +5,10 @@ builds `nr.Renderer(camera_mode='projection', light_intensity_ambient=1.0,
 light_intensity_directional=0., K=K, R=R, t=t, near=.., far=.., image_size=S, orig_size=S,
 fill_back=True, background_color=[1,1,1])` (renderer.py:47-54) and calls
 `.render_depth(vertices [B,N,3] f32, faces [B,F,3] i32) -> [B,S,S] f32` (renderer.py:120),
-differentiable w.r.t. `vertices`.  `.render_rgb` (renderer.py:196,230,248,272,275) is reachable
-only from visualisation helpers nothing calls; it raises NotImplementedError here.
+differentiable w.r.t. `vertices`.  `.render_rgb(vertices, faces, textures [B,F,T,T,T,C])`
+(renderer.py:196,230,248,272,275 — the visualisation helpers) is the forward texture pass
+(g2s_raster_rgb_fwd); it returns a tensor without autograd history (the reference never
+differentiates through it; the package's silhouette-gradient kernels are not rebuilt).
 
 Semantics follow SURVEY.md Appendix A (the package itself is un-vendored and un-pinned, so parity
 is checked against the oracle's restatement, not against the CUDA original):
@@ -115,6 +117,8 @@ class Renderer:
         self.dist_coeffs = dist_coeffs
         self.orig_size = orig_size
         self.near, self.far = near, far
+        self.light_intensity_ambient = light_intensity_ambient
+        self.light_intensity_directional = light_intensity_directional
         self.rasterizer_eps = 1e-3
         self._K_host = None
 
@@ -185,8 +189,59 @@ class Renderer:
             raise NotImplementedError("per-sample face lists are not supported: call per sample")
         return f0
 
-    def render_rgb(self, *a, **k):
-        raise NotImplementedError("render_rgb (texture path) is outside the GAN2Shape training hot "
-                                  "path (renderer.py:141-250 is never called); see SURVEY.md §8f")
+    def render_rgb(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        """[B, C, S, S] image of the textured mesh: rasterize with the constructor's near / far
+        (renderer.py:51), read each winning face's texture cube trilinearly at perspective-corrected
+        barycentric coordinates, background colour elsewhere, flip + 2x2 average.  Lighting: ambient
+        only (GAN2Shape builds the renderer with light_intensity_ambient=1, directional=0)."""
+        K = self.K if K is None else K
+        R = self.R if R is None else R
+        t = self.t if t is None else t
+        orig_size = self.orig_size if orig_size is None else orig_size
+        if self.light_intensity_directional != 0:
+            raise NotImplementedError("directional lighting is not supported (GAN2Shape uses ambient light only)")
+        if K is None:
+            raise ValueError("camera_mode='projection' needs K")
+        _lib.require_cuda(vertices, textures)
+        with torch.no_grad():
+            vertices = vertices.detach().float()
+            if self._needs_transform(R, t):
+                if R is not None:
+                    vertices = torch.matmul(vertices, R.reshape(-1, 3, 3).transpose(2, 1))
+                if t is not None:
+                    vertices = vertices + t.reshape(-1, 1, 3)
+            verts = vertices.contiguous()
+            B, N, _ = verts.shape
+            S = self.image_size
+            f = self._shared_faces(faces, N, S)
+            F = 2 * (S - 1) * (S - 1) if f is None else f.shape[0]
+            tex = textures.detach().float().contiguous()
+            if tex.dim() != 6 or tex.shape[0] != B or tex.shape[1] != F or not (tex.shape[2] == tex.shape[3] == tex.shape[4]):
+                raise ValueError(f"textures must be [B={B}, F={F}, T, T, T, C], got {tuple(tex.shape)}")
+            ts, C = tex.shape[2], tex.shape[5]
+            if self.light_intensity_ambient != 1:
+                tex = tex * float(self.light_intensity_ambient)
+            ssaa = 2 if self.anti_aliasing else 1
+            L = _lib.load()
+            depth = torch.empty((B, S, S), dtype=torch.float32, device=verts.device)
+            fidx = torch.empty((B, S * ssaa, S * ssaa), dtype=torch.int32, device=verts.device)
+            bary = torch.empty((B, S * ssaa, S * ssaa, 3), dtype=torch.float32, device=verts.device)
+            ws = _workspace(verts.device, L.g2s_raster_workspace_bytes(B, N, F, S))
+            Kc = (_lib.C.c_float * 9)(*self._host_K(K))
+            _lib.check(L.g2s_raster_depth_fwd(_lib.ptr(verts), _lib.ptr(f), B, N, F, S, Kc, float(orig_size), ssaa,
+                                              int(bool(self.fill_back)), float(self.near), float(self.far),
+                                              _lib.ptr(depth), _lib.ptr(fidx), _lib.ptr(bary), _lib.ptr(ws),
+                                              ws.numel(), _lib.stream()))
+            bg = [float(v) for v in self.background_color][:C]
+            bg += [bg[-1]] * (C - len(bg))
+            rgb = torch.empty((B, C, S, S), dtype=torch.float32, device=verts.device)
+            _lib.check(L.g2s_raster_rgb_fwd(_lib.ptr(verts), _lib.ptr(f), _lib.ptr(fidx), _lib.ptr(bary), _lib.ptr(tex),
+                                            B, N, F, S, ssaa, ts, C, (_lib.C.c_float * C)(*bg),
+                                            float(self.rasterizer_eps), _lib.ptr(rgb), _lib.stream()))
+        return rgb
 
-    render = render_silhouettes = render_rgb
+    def render(self, *a, **k):
+        raise NotImplementedError("render / render_silhouettes (alpha channel, silhouette gradients) are not part "
+                                  "of the boundary GAN2Shape uses (renderer.py:120,196)")
+
+    render_silhouettes = render

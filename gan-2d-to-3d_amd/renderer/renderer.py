@@ -5,8 +5,9 @@ behind `warp_canon_depth` is the libg2s kernel (through the neural_renderer drop
 that do not change results: tensors are created on `device` directly (the reference hard-codes
 .cuda()); the pixel grid, face list and rotation centre are built once; `grid_sample` gets
 `align_corners=True` explicitly (the reference targets torch 1.2 where that was the only
-behaviour).  render_yaw / render_view / downscale_K and the
-grid_sample=False branch of render_given_view (render_rgb texture path) are out of scope.
+behaviour).  The visualisation helpers — render_yaw, render_view, the
+grid_sample=False branch of render_given_view (renderer.py:141-277), downscale_K — go through the
+texture path of the rasterizer (`render_rgb`); their pose sweeps share one helper (`_sweep`).
 """
 import math
 
@@ -15,7 +16,7 @@ import torch.nn as nn
 
 from .. import fused_geometry as fg
 from ..plugins import neural_renderer as nr
-from .utils import get_face_idx, get_grid, get_transform_matrices
+from .utils import get_face_idx, get_grid, get_textures_from_im, get_transform_matrices
 
 EPS = 1e-7
 
@@ -175,10 +176,106 @@ class Renderer():
         normal = normal + self._const(("border", h, w, str(depth.device)), make_border)
         return normal / (((normal ** 2).sum(3, keepdim=True)) ** 0.5 + EPS)
 
+    def downscale_K(self, downscale):
+        """renderer.py:56-59."""
+        if downscale > 1:
+            self.K = torch.cat((self.K_origin[:, 0:2] / downscale, self.K_origin[:, 2:]), dim=1)
+            self.inv_K = torch.inverse(self.K[0]).unsqueeze(0)
+            self._rays.clear()
+            self._K9 = tuple(float(v) for v in self.K[0].reshape(9).tolist())
+            # like the reference, the nr.Renderer built in __init__ keeps the original intrinsics
+
+    # ------------------------------------------------------------------ texture path (visualisation)
+    def _render_textured(self, verts, im):
+        """render_rgb of the grid mesh `verts` (b, h*w, 3) coloured by `im` (b, c, h, w), clamped to
+        [-1, 1] (renderer.py:196,272)."""
+        b, c, h, w = im.shape
+        faces = get_face_idx(b, h, w, device=im.device)
+        textures = get_textures_from_im(im, tx_size=self.tex_cube_size)
+        return self.renderer.render_rgb(verts, faces, textures).clamp(min=-1., max=1.)
+
+    def _warp_by_grid_sample(self, im, depth, view):
+        self.set_transform_matrices(view)
+        recon_depth = self.warp_canon_depth(depth)
+        grid = self.get_inv_warped_2d_grid(recon_depth)
+        return nn.functional.grid_sample(im, grid, mode='bilinear', align_corners=True)
+
+    def _canonical_mesh(self, depth, v_before):
+        """Vertices of the depth mesh, taken back to the canonical pose when the depth was predicted
+        under view `v_before` (renderer.py:166-170,208-212)."""
+        b = depth.shape[0]
+        verts = self.depth_to_3d_grid(depth).reshape(b, -1, 3)
+        if v_before is not None:
+            rot_mat, trans_xyz = get_transform_matrices(v_before)
+            verts = self.rotate_pts(self.translate_pts(verts, -trans_xyz), rot_mat.transpose(2, 1))
+        return verts
+
+    def _sweep(self, im, depth, poses, v_before, v_after, grid_sample, verts):
+        """One rendering per pose = (rx, ry, rz) angle triple -> (b, len(poses), c, h, w)."""
+        b = im.shape[0]
+        frames = []
+        for i, angles in enumerate(poses):
+            if grid_sample:
+                view = torch.tensor([list(angles) + [0., 0., 0.]], dtype=torch.float32, device=im.device)
+                if v_before is not None:
+                    view = view - v_before
+                frames.append(self._warp_by_grid_sample(im, depth, view))
+                continue
+            rot_i, _ = get_transform_matrices(torch.tensor([list(angles)], dtype=torch.float32, device=im.device))
+            posed = self.rotate_pts(verts, rot_i.repeat(b, 1, 1))
+            if v_after is not None:
+                v_i = v_after[i] if v_after.dim() == 3 else v_after
+                rot_mat, trans_xyz = get_transform_matrices(v_i)
+                posed = self.translate_pts(self.rotate_pts(posed, rot_mat), trans_xyz)
+            frames.append(self._render_textured(posed, im))
+        return torch.stack(frames, 1)
+
+    def render_yaw(self, im, depth, v_before=None, v_after=None, rotations=None, maxr=90, nsample=9,
+                   grid_sample=False, crop_mesh=None):
+        """Yaw sweep of the textured depth mesh (renderer.py:141-198)."""
+        grid_3d = self.depth_to_3d_grid(depth)
+        if crop_mesh is not None:   # flatten the border band onto its inner neighbour (renderer.py:145-158)
+            grid_3d = grid_3d.clone()
+            top, bottom, left, right = crop_mesh
+            if top > 0:
+                grid_3d[:, :top, :, 1:] = grid_3d[:, top:top + 1, :, 1:]
+            if bottom > 0:
+                grid_3d[:, -bottom:, :, 1:] = grid_3d[:, -bottom - 1:-bottom, :, 1:]
+            if left > 0:
+                grid_3d[:, :, :left, 0::2] = grid_3d[:, :, left:left + 1, 0::2]
+            if right > 0:
+                grid_3d[:, :, -right:, 0::2] = grid_3d[:, :, -right - 1:-right, 0::2]
+        b = im.shape[0]
+        verts = grid_3d.reshape(b, -1, 3)
+        if v_before is not None:
+            rot_mat, trans_xyz = get_transform_matrices(v_before)
+            verts = self.rotate_pts(self.translate_pts(verts, -trans_xyz), rot_mat.transpose(2, 1))
+        if rotations is None:
+            rotations = torch.linspace(-math.pi / 180 * maxr, math.pi / 180 * maxr, nsample)
+        poses = [(0., float(r), 0.) for r in rotations]
+        return self._sweep(im, depth, poses, v_before, v_after, grid_sample, verts)
+
+    def render_view(self, im, depth, v_before=None, rotations=None, maxr=[20, 90], nsample=[5, 9],
+                    grid_sample=False):
+        """Yaw sweep followed by a pitch sweep (renderer.py:200-250)."""
+        verts = self._canonical_mesh(depth, v_before)
+        pitch = torch.linspace(-math.pi / 180 * maxr[0], math.pi / 180 * maxr[0], nsample[0])
+        yaw = torch.linspace(-math.pi / 180 * maxr[1], math.pi / 180 * maxr[1], nsample[1])
+        poses = [(0., float(y), 0.) for y in yaw] + [(float(p), 0., 0.) for p in pitch]
+        return self._sweep(im, depth, poses, v_before, None, grid_sample, verts)
+
     def render_given_view(self, im, depth, view, mask=None, grid_sample=True):
+        """renderer.py:252-277: warp `im` (and `mask`) to `view` — by inverse-warp sampling
+        (grid_sample=True, the training path) or by rendering the textured mesh."""
         if not grid_sample:
-            raise NotImplementedError("render_given_view(grid_sample=False) uses render_rgb "
-                                      "(texture path): outside the training hot path")
+            b = im.shape[0]
+            rot_mat, trans_xyz = get_transform_matrices(view)
+            verts = self.depth_to_3d_grid(depth).reshape(b, -1, 3)
+            verts = self.translate_pts(self.rotate_pts(verts, rot_mat), trans_xyz)
+            warped_images = self._render_textured(verts, im)
+            if mask is not None:
+                return warped_images, self._render_textured(verts, mask)
+            return warped_images
         self.set_transform_matrices(view)
         recon_depth = self.warp_canon_depth(depth)
         grid_2d_from_canon = self.get_inv_warped_2d_grid(recon_depth)

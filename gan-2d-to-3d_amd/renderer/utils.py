@@ -1,6 +1,7 @@
 """Mirror of the hot-path helpers of GAN2Shape/renderer/utils.py (get_grid :22-30,
-get_rotation_matrix :33-49, get_transform_matrices :52-73, get_face_idx :76-80).  The texture-cube
-helpers (:83-109) only feed render_rgb and are out of scope.
+get_rotation_matrix :33-49, get_transform_matrices :52-73, get_face_idx :76-80) and of the
+texture-cube helpers that feed render_rgb (vcolor_to_texture_cube :83-96, get_textures_from_im
+:99-109).
 
 Device-agnostic torch code (the -m "not gpu" tests pin it against the golden vectors on CPU);
 everything is created directly on the device of its input instead of on the CPU + .to(device).
@@ -64,3 +65,40 @@ def get_face_idx(b, h, w, device=None):
     if h == w:
         out._g2s_regular_grid = h
     return out
+
+
+def _cube_coefficients(device):
+    """(8, 3): weight of vertex colour v at cube corner e = (e0, e1, e2), flattened e0*4 + e1*2 + e2,
+    such that trilinear interpolation of the cube at barycentric coordinates (w0, w1, w2), w0 + w1 +
+    w2 = 1, gives sum_v w_v c_v.  By the number n of set coordinates: n = 0 -> 1/2 each; n = 1 -> the
+    vertex of that axis; n = 2 -> +1/2 for the two set axes, -1/2 for the third; n = 3 -> 0."""
+    rows = []
+    for corner in range(8):
+        e = [(corner >> 2) & 1, (corner >> 1) & 1, corner & 1]
+        n = sum(e)
+        rows.append({0: [0.5] * 3, 1: [float(x) for x in e], 2: [0.5 if x else -0.5 for x in e], 3: [0.0] * 3}[n])
+    return torch.tensor(rows, dtype=torch.float32, device=device)
+
+
+def vcolor_to_texture_cube(vcolors):
+    """vertex colours (b, c, n, 3) -> texture cubes (b, n, 2, 2, 2, c)  (renderer/utils.py:83-96)."""
+    b, c, n, _ = vcolors.shape
+    cube = torch.matmul(_cube_coefficients(vcolors.device), vcolors.permute(0, 2, 3, 1))   # (b, n, 8, c)
+    return cube.reshape(b, n, 2, 2, 2, c)
+
+
+def get_textures_from_im(im, tx_size=1):
+    """Per-face textures of the regular-grid mesh from an image (b, c, h, w)
+    (renderer/utils.py:99-109).  tx_size 1: one colour per face — pixel (i, j) for faces1, pixel
+    (i+1, j+1) for faces2.  tx_size 2: a 2x2x2 cube per face from the colours at the quad corners, in
+    the reference's order ((i,j), (i,j+1), (i+1,j)) / ((i+1,j), (i,j+1), (i+1,j+1))."""
+    b, c, h, w = im.shape
+    tl, tr, bl, br = im[:, :, :h - 1, :w - 1], im[:, :, :h - 1, 1:], im[:, :, 1:, :w - 1], im[:, :, 1:, 1:]
+    if tx_size == 1:
+        flat = torch.cat([tl.reshape(b, c, -1), br.reshape(b, c, -1)], 2)
+        return flat.transpose(2, 1).reshape(b, -1, 1, 1, 1, c)
+    if tx_size == 2:
+        first = torch.stack([tl, tr, bl], -1).reshape(b, c, -1, 3)
+        second = torch.stack([bl, tr, br], -1).reshape(b, c, -1, 3)
+        return vcolor_to_texture_cube(torch.cat([first, second], 2))
+    raise NotImplementedError("Currently support texture size of 1 or 2 only.")

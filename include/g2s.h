@@ -85,6 +85,18 @@ int g2s_raster_depth_bwd(const float *verts, const int32_t *faces, const float *
                          int n_faces, int S, const float *K, float orig_size, int ssaa,
                          float *grad_verts, g2s_stream_t stream);
 
+/* Texture path: nr.Renderer.render_rgb(vertices, faces, textures [B,F,ts,ts,ts,C]) as the reference's
+ * visualisation helpers call it (GAN2Shape/renderer/renderer.py:196,230,248,272,275).  Forward only.
+ * Second pass over the maps g2s_raster_depth_fwd saves (run it with the constructor's near / far,
+ * renderer.py:51): trilinear read of the winning face's texture cube at perspective-corrected
+ * barycentric coordinates (eps = rasterizer_eps, 1e-3 in the package), `background` (HOST pointer, C
+ * floats) where no face covers the sample, then the vertical flip + ssaa x ssaa average.
+ * rgb_out [B, C, S, S].  PARITY UNPINNED like the depth path. */
+int g2s_raster_rgb_fwd(const float *verts, const int32_t *faces, const int32_t *face_idx,
+                       const float *bary, const float *textures, int B, int n_verts, int n_faces, int S,
+                       int ssaa, int ts, int C, const float *background, float eps, float *rgb_out,
+                       g2s_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * fused bias + activation.
  * Replaces fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)

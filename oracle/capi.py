@@ -131,3 +131,24 @@ def render_depth_bwd(verts, faces, grad_depth, face_idx, bary, S, K, orig_size=N
             _p(gv, ct))
     assert rc == 0
     return gv
+
+
+def render_rgb(verts, faces, textures, S, K, orig_size=None, ssaa=2, fill_back=True, near=0.1, far=10.0,
+               background=(1.0, 1.0, 1.0), eps=1e-3, dtype=np.float32):
+    """neural_renderer Renderer.render_rgb (external; recalled semantics, PARITY UNPINNED).
+    textures (B, F, ts, ts, ts, C).  Returns (B, C, S, S)."""
+    ct, suf = _real(dtype)
+    d = render_depth(verts, faces, S, K, orig_size, ssaa, fill_back, near, far, dtype)
+    verts = np.ascontiguousarray(verts, dtype)
+    faces = np.ascontiguousarray(faces, np.int32)
+    textures = np.ascontiguousarray(textures, dtype)
+    B, N, _ = verts.shape
+    F, ts, Cc = faces.shape[0], textures.shape[2], textures.shape[5]
+    bg = np.ascontiguousarray(np.asarray(background, dtype)[:Cc])
+    out = np.empty((B, Cc, S, S), dtype)
+    fn = getattr(lib(), "g2s_oracle_render_rgb" + suf)
+    rc = fn(_p(verts, ct), _p(faces, C.c_int), _p(d["face_idx"], C.c_int), _p(d["bary"], ct), _p(textures, ct),
+            C.c_int(B), C.c_int(N), C.c_int(F), C.c_int(S), C.c_int(ssaa), C.c_int(ts), C.c_int(Cc), _p(bg, ct),
+            ct(eps), _p(out, ct))
+    assert rc == 0
+    return out

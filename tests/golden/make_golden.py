@@ -137,6 +137,15 @@ def geometry_golden():
         out[f"rot{n}"] = np_(r)
         out[f"trans{n}"] = np_(t)
 
+    # texture-cube helpers feeding render_rgb (renderer/utils.py:83-109)
+    torch.manual_seed(2)
+    im = torch.randn(2, 3, 4, 5)
+    out["tex.im"] = np_(im)
+    out["tex.size1"] = np_(ru.get_textures_from_im(im, tx_size=1))
+    out["tex.size2"] = np_(ru.get_textures_from_im(im, tx_size=2))
+    vc = torch.randn(1, 2, 3, 3)
+    out["tex.vcolors"], out["tex.cube"] = np_(vc), np_(ru.vcolor_to_texture_cube(vc))
+
     # Renderer geometry: import renderer.py with an import-only placeholder for neural_renderer
     # (gives the pure-torch geometry methods; render_depth stays unavailable).
     sys.modules.setdefault("neural_renderer", types.ModuleType("neural_renderer"))

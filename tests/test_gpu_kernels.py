@@ -456,3 +456,70 @@ def test_trained_nets_fused_match_modules(g2s, name):
         err2 += e * e
         ref2 += float(b.norm()) ** 2
     assert err2 ** 0.5 <= 5e-3 * ref2 ** 0.5
+
+
+# ----------------------------------------------------------------------------- render_rgb (texture path)
+@pytest.mark.parametrize("S,ts,C,fill_back,implicit", [
+    (16, 2, 3, True, True), (16, 1, 3, True, True), (20, 2, 3, True, False), (12, 2, 1, False, True),
+    (32, 2, 3, True, True)])
+def test_render_rgb_vs_oracle(g2s, S, ts, C, fill_back, implicit):
+    """nr.Renderer.render_rgb (g2s_raster_depth_fwd with saved maps + g2s_raster_rgb_fwd) against the
+    oracle's texture pass on posed, folded meshes: same winners (bit-exact depth path) and the same
+    arithmetic for the cube read -> 1e-6."""
+    from gan2shape_amd.plugins import neural_renderer as nr
+    geo, verts, faces = scene(S, B=2, seed=S + ts + C)
+    rng = np.random.default_rng(S)
+    tex = rng.uniform(-1, 1, (2, faces.shape[0], ts, ts, ts, C)).astype(np.float32)
+    bg = [1.0, 0.5, -0.25][:C]
+    ref = capi.render_rgb(verts, faces, tex, S, geo.K[0], fill_back=fill_back, near=0.1, far=10.0, background=bg)
+    r = nr.Renderer(camera_mode='projection', K=dev(geo.K), image_size=S, orig_size=S, fill_back=fill_back,
+                    near=0.1, far=10.0, light_intensity_ambient=1.0, light_intensity_directional=0.0,
+                    background_color=bg)
+    f = None if implicit else dev(faces, torch.int32)[None].expand(2, -1, -1)
+    if implicit:
+        from gan2shape_amd.renderer.utils import get_face_idx
+        f = get_face_idx(2, S, S, device="cuda")
+    out = r.render_rgb(dev(verts), f, dev(tex))
+    assert tuple(out.shape) == (2, C, S, S) and not out.requires_grad
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_renderer_texture_helpers_on_gpu(g2s):
+    """render_given_view(grid_sample=False), render_yaw, render_view (renderer.py:141-277): the mesh
+    rendering of a smooth image under a small pose agrees with the inverse-warp sampling of the same
+    pose away from silhouettes; the zero pose of a sweep reproduces the identity rendering; the
+    sweeps have the reference's frame counts."""
+    from gan2shape_amd.renderer import Renderer
+    S = 64
+    R = Renderer({"rot_center_depth": 1.0, "fov": 10, "tex_cube_size": 2}, S, 0.9, 1.1, device="cuda")
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, S), torch.linspace(-1, 1, S), indexing="ij")
+    depth = (1.0 - 0.06 * torch.exp(-(xx ** 2 + yy ** 2) * 2))[None].cuda()
+    im = torch.stack([torch.sin(3 * xx), torch.cos(2 * yy), xx * yy])[None].cuda()
+    # the reference builds the renderer with a white background (renderer.py:54): a ZERO mask marks
+    # the covered pixels (0 inside, 1 where only background is seen).  The mesh renderer samples at
+    # pixel + 0.5 (SURVEY Appendix A item 3): compare with the warp shifted by half a pixel.
+    for k, val in enumerate([0.0, 0.05, -0.08, 0.02, 0.01, -0.01, 0.02]):
+        view = torch.zeros(1, 6, device="cuda")
+        if k:
+            view[0, k - 1] = val
+        mesh, mesh_mask = R.render_given_view(im, depth, view, mask=torch.zeros_like(im), grid_sample=False)
+        warp = R.render_given_view(im, depth, view, grid_sample=True)
+        inside = (mesh_mask[:, :1] < 0.001).expand_as(im).clone()
+        inside[..., :3, :] = inside[..., -3:, :] = False
+        inside[..., :, :3] = inside[..., :, -3:] = False
+        assert inside.float().mean() > 0.6
+        shifted = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(warp, (0, 1, 0, 1), mode="replicate"), 2, stride=1)
+        err = float((mesh - shifted)[inside].abs().max())
+        assert err < (1e-3 if k == 0 else 0.06), (k, err)     # identity pose: the same picture to 1e-4
+    yaw = R.render_yaw(im, depth, maxr=20, nsample=5)
+    assert tuple(yaw.shape) == (1, 5, 3, S, S)
+    ident = R.render_given_view(im, depth, torch.zeros(1, 6, device="cuda"), grid_sample=False)
+    torch.testing.assert_close(yaw[:, 2], ident, rtol=1e-5, atol=1e-5)
+    sweep = R.render_view(im, depth, maxr=[10, 20], nsample=[3, 5])
+    assert tuple(sweep.shape) == (1, 8, 3, S, S)
+    torch.testing.assert_close(sweep[:, 2], ident, rtol=1e-5, atol=1e-5)     # middle yaw = 0
+    torch.testing.assert_close(sweep[:, 6], ident, rtol=1e-5, atol=1e-5)     # middle pitch = 0
+    gs = R.render_yaw(im, depth, maxr=20, nsample=3, grid_sample=True)
+    assert tuple(gs.shape) == (1, 3, 3, S, S) and bool(torch.isfinite(gs).all())
+    crop = R.render_yaw(im, depth, maxr=10, nsample=3, crop_mesh=(2, 2, 3, 3))
+    assert tuple(crop.shape) == (1, 3, 3, S, S)

@@ -113,6 +113,13 @@ def test_renderer_utils_golden(golden):
         np.testing.assert_array_equal(t.numpy(), g[f"trans{n}"])
     with pytest.raises(Exception):
         ru.get_transform_matrices(torch.zeros(1, 4))
+    # texture-cube helpers (renderer/utils.py:83-109)
+    im = T(g["tex.im"])
+    np.testing.assert_array_equal(ru.get_textures_from_im(im, 1).numpy(), g["tex.size1"])
+    np.testing.assert_allclose(ru.get_textures_from_im(im, 2).numpy(), g["tex.size2"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(ru.vcolor_to_texture_cube(T(g["tex.vcolors"])).numpy(), g["tex.cube"], rtol=1e-6, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        ru.get_textures_from_im(im, 3)
 
 
 def test_renderer_geometry_golden(golden):

@@ -164,3 +164,67 @@ def test_f32_close_to_f64_on_random_view():
     same = o32["face_idx"] == o64["face_idx"]
     assert same.mean() > 0.995
     np.testing.assert_allclose(o32["depth_ss"][same], o64["depth_ss"][same], rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- render_rgb (texture pass)
+def _np_textures(im, tx_size):
+    import torch
+    from gan2shape_amd.renderer import utils as ru
+    return ru.get_textures_from_im(torch.as_tensor(im), tx_size).numpy()
+
+
+def test_render_rgb_constant_texture_and_background():
+    """A constant colour comes back unchanged wherever the mesh covers all 4 supersamples, the
+    background colour where nothing does, their average on the silhouette (last row / column:
+    Appendix A item 3)."""
+    S = 8
+    geo, verts, faces = _canon(S, np.full((1, S, S), 1.0))
+    im = np.broadcast_to(np.array([0.25, -0.5, 0.75], np.float32)[None, :, None, None], (1, 3, S, S)).copy()
+    for ts in (1, 2):
+        out = capi.render_rgb(verts, faces, _np_textures(im, ts), S, geo.K[0], background=(1, 1, 1))
+        np.testing.assert_allclose(out[0, :, :S - 1, :S - 1], im[0, :, :S - 1, :S - 1], atol=2e-6)
+        np.testing.assert_array_equal(out[0, :, S - 1, :], 1.0)
+        np.testing.assert_array_equal(out[0, :, :, S - 1], 1.0)
+
+
+def test_render_rgb_texture_cube_is_barycentric_interpolation():
+    """tx_size = 2 (renderer/utils.py:83-109): trilinear reading of the 2x2x2 cube at the barycentric
+    weights interpolates the face's three vertex colours (up to the package's eps = 1e-3 on the cube
+    coordinates).  On a fronto-parallel plane the colours handed to a face in the REFERENCE's order
+    make every output pixel a fixed convex combination of its quad's corner colours."""
+    S = 12
+    geo, verts, faces = _canon(S, np.full((1, S, S), 1.0))
+    yy, xx = np.meshgrid(np.arange(S), np.arange(S), indexing="ij")
+    ramp = np.stack([0.05 * xx, 0.03 * yy, 0.02 * xx + 0.01 * yy]).astype(np.float32)[None]
+    out = capi.render_rgb(verts, faces, _np_textures(ramp, 2), S, geo.K[0], dtype=np.float64)
+    # supersample (r + a, c + b), a, b in {.25, .75}: a + b < 1 lies in faces1 = (i,j),(i+1,j),(i,j+1)
+    # with weights (1-a-b, a, b) and the colours tl, tr, bl in that order; a + b > 1 in faces2 =
+    # (i,j+1),(i+1,j),(i+1,j+1) with weights (1-a, 1-b, a+b-1) and colours bl, tr, br; a + b = 1: faces1
+    tl, tr, bl, br = ramp[0, :, :-1, :-1], ramp[0, :, :-1, 1:], ramp[0, :, 1:, :-1], ramp[0, :, 1:, 1:]
+    exp = 0
+    for a in (.25, .75):
+        for b in (.25, .75):
+            if a + b <= 1:
+                exp = exp + (1 - a - b) * tl + a * tr + b * bl
+            else:
+                exp = exp + (1 - a) * bl + (1 - b) * tr + (a + b - 1) * br
+    np.testing.assert_allclose(out[0, :, :S - 1, :S - 1], exp / 4, atol=3e-3)   # eps = 1e-3 of the cube edge
+
+
+def test_render_rgb_fill_back_uses_the_permuted_cube():
+    """A mesh seen from behind is drawn through the reversed copies of its faces, whose cubes are
+    textures.permute(0,1,4,3,2,5): the picture equals the front view of the mirrored mesh."""
+    S = 10
+    rng = np.random.default_rng(0)
+    im = rng.uniform(-1, 1, (1, 3, S, S)).astype(np.float32)
+    geo, verts, faces = _canon(S, np.full((1, S, S), 1.0))
+    tex = _np_textures(im, 2)
+    front = capi.render_rgb(verts, faces, tex, S, geo.K[0], fill_back=True)
+    nofill = capi.render_rgb(verts, faces, tex, S, geo.K[0], fill_back=False)
+    np.testing.assert_array_equal(front, nofill)            # front-facing: the copies never win
+    flipped = faces[:, ::-1].copy()                         # every face back-facing
+    back_only = capi.render_rgb(verts, flipped, tex, S, geo.K[0], fill_back=False)
+    np.testing.assert_array_equal(back_only, 1.0)           # nothing drawn without fill_back
+    tex_rev = np.ascontiguousarray(tex.transpose(0, 1, 4, 3, 2, 5))
+    both = capi.render_rgb(verts, flipped, tex_rev, S, geo.K[0], fill_back=True)
+    np.testing.assert_allclose(both, front, atol=1e-6)      # reversed order + permuted cube = the original
