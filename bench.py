@@ -42,7 +42,25 @@ PATTERN = [1] * 7 + [2] * 7 + [3] * 6   # main.py:148 stage 0 = {700, 700, 600}
 F32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 
 
-def face_config(n_proj=8):
+WORKLOADS = {
+    # BASELINE.json configs[1]: the headline — configs/face.yml at 128x128, fp32 (the reference's arithmetic)
+    "face128_n8": dict(image_size=128, gan_size=128, prior_name='ellipsoid', mfma_operands='f32', dtype="f32"),
+    # BASELINE.json configs[4]: 256x256, confidence-map prior, fp16 operands / fp32 accumulation for the
+    # frozen G / D / VGG GEMMs (a non-reference extension: SURVEY.md §8d config 5) — its own JSON line,
+    # never the headline
+    "face256_fp16": dict(image_size=256, gan_size=256, prior_name='confidence', mfma_operands='f16', dtype="f16"),
+}
+
+
+def face_config(n_proj=8, workload="face128_n8"):
+    wl = WORKLOADS[workload]
+    cfg = _face_config(n_proj)
+    cfg.update(image_size=wl["image_size"], gan_size=wl["gan_size"], prior_name=wl["prior_name"],
+               mfma_operands=wl["mfma_operands"])
+    return cfg
+
+
+def _face_config(n_proj=8):
     return {
         'image_size': 128, 'z_dim': 512, 'gan_size': 128, 'channel_multiplier': 1,
         'gan_ckpt_path': None, 'n_proj_samples': n_proj, 'category': 'face',
@@ -60,7 +78,7 @@ def face_config(n_proj=8):
 
 def synthetic_sample(model, seed, device):
     g = torch.Generator().manual_seed(seed)
-    img = torch.randn(1, 3, 32, 32, generator=g)
+    img = torch.randn(1, 3, model.image_size // 4, model.image_size // 4, generator=g)
     img = torch.tanh(torch.nn.functional.interpolate(img, scale_factor=4, mode='bilinear')).to(device)
     with torch.no_grad():
         w = model.generator.style_forward(torch.randn(1, 512, generator=g).to(device))
@@ -367,6 +385,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n-proj", type=int, default=8)
+    ap.add_argument("--workload", default="face128_n8", choices=sorted(WORKLOADS),
+                    help="face128_n8 = the BASELINE metric's configuration (default); face256_fp16 = BASELINE "
+                         "config 5 (256x256, fp16-operand MFMA), reported on its own line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graphs)")
     ap.add_argument("--only", type=int, default=0, choices=[0, 1, 2, 3],
@@ -397,7 +418,7 @@ def main():
     lib.load()
 
     torch.manual_seed(0)  # identical random-init weights on every rank
-    cfg = face_config(args.n_proj)
+    cfg = face_config(args.n_proj, args.workload)
     trainer = Trainer(GAN2Shape, cfg, device=device, capturable=not args.eager)
     image, latent = synthetic_sample(trainer.model, 1234 + rank, device)
     torch.manual_seed(1234 + rank)
@@ -518,9 +539,10 @@ def main():
             "value": rate, "unit": "iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "face128_n8" if args.n_proj == 8 else f"face128_n{args.n_proj}",
-                       "image_size": 128, "gan_size": 128, "n_proj_samples": args.n_proj,
+            "scaling": "weak", "vs_baseline": None, "dtype": WORKLOADS[args.workload]["dtype"], "data": "synthetic",
+            "config": {"workload": args.workload if args.n_proj == 8 else f"{args.workload.rsplit('_', 1)[0]}_n{args.n_proj}",
+                       "image_size": cfg['image_size'], "gan_size": cfg['gan_size'], "n_proj_samples": args.n_proj,
+                       "mfma_operands": cfg['mfma_operands'], "prior": cfg['prior_name'],
                        "step_mix": "7:7:6 (step1:step2:step3, main.py:148 stage 0)" if not args.only
                        else f"step{args.only} only (analysis run, not the BASELINE metric)",
                        "images_per_rank": 1, "sharding": "one image per rank, no collective"},
@@ -528,9 +550,12 @@ def main():
             "launch_mode": "eager" if args.eager else "hipGraph replay (one graph per step kind)",
             "final_loss": final_loss,
             "roofline": roofline,
-            "roofline_other": roofline_other(device) if world == 1 else None,
+            "roofline_other": roofline_other(device) if world == 1 and args.workload == "face128_n8" else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.workload != "face128_n8":
+            out["roofline"]["peak_note"] = ("fp16-operand launches are priced against the fp32 matrix peak here; "
+                                            "the dense fp16 MFMA peak is ~2500 TFLOP/s")
+        if world == 1 and not args.no_cpu_baseline and args.workload == "face128_n8":
             out["cpu_baseline"] = cpu_baseline(args.n_proj)
         else:
             out["cpu_baseline"] = None

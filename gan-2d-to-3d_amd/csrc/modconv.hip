@@ -374,6 +374,215 @@ __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// fp16-OPERAND variant (BASELINE config 5: "fp16 MFMA path"): same geometry machinery, tensors stay
+// fp32 in HBM, both GEMM operands are rounded to fp16 (RTNE) on their way into LDS and multiplied
+// by v_mfma_f32_32x32x8_f16 with fp32 accumulation — 16x the matrix rate of the fp32 MFMA, half the
+// LDS bytes.  NOT used by the headline (fp32) workload: results differ from fp32 at the 1e-3 level.
+// Deliberately simple schedule: one LDS buffer, {gather + convert + write, barrier, MFMAs, barrier}
+// per K tile; latencies overlap across the 2-3 workgroups a CU holds (LDS 37 KB, < 170 registers).
+// LDS images are [row][k] with k contiguous (4 halves = one MFMA operand = one ds_read_b64).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int T> struct KTile16 {       // channels per K tile such that K = CPT * T is a multiple of 8
+    static constexpr int CPT = (T == 9) ? 8 : (T == 4) ? 8 : (T == 2) ? 16 : 32;
+    static constexpr int KT = CPT * T;  // 72, 32, 32, 32
+};
+
+template <int BM, int BN, int T, bool SCALE>
+__device__ __forceinline__ void modconv_f16_body(const ConvDesc &d, const ConvClass &c, _Float16 *As, _Float16 *Bs,
+                                                 const int (&stab)[25], const int tile_id) {
+    constexpr int CPT = KTile16<T>::CPT, KT = KTile16<T>::KT, KTP = KT + 4;   // +4 halves: bank spread
+    constexpr int WMT = BM / 64, WNT = BN / 64;
+    constexpr int GA = (BM * (KT / 4) + NTHREADS - 1) / NTHREADS;   // groups of 4 consecutive k per thread
+    constexpr int GB = (BN * (KT / 4) + NTHREADS - 1) / NTHREADS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lk = lane >> 5;
+    const int Ncls = d.B * c.OH * c.OW;
+    const int tiles_m = (d.M + BM - 1) / BM;
+    const int m0 = (tile_id % tiles_m) * BM;
+    const int n0 = (tile_id / tiles_m) * BN;
+    const int ktiles = (d.Cr + CPT - 1) / CPT;
+    const int per = (ktiles + d.splitk - 1) / d.splitk;
+    const int kt_begin = blockIdx.y * per;
+    const int kt_end = min(ktiles, kt_begin + per);
+    const int HW = d.H * d.W;
+    constexpr int OOB = 0x7fffffff;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, d.B * d.Cr * HW * 4, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)d.w, 0, d.w_bytes, 0x00020000);
+    const auto rsc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(SCALE ? d.in_scale : d.w), 0, SCALE ? d.B * d.Cr * 4 : 4, 0x00020000);
+
+    // ---- im2col groups: column n = gidx % BN (coalesced pixels), k = 4 * (gidx / BN) .. + 3
+    int offB[GB][4], offS[GB][4];
+    unsigned dchB[GB];          // 4 x 8 bits: channel-in-tile of each element (partial last tile)
+#pragma unroll
+    for (int e = 0; e < GB; e++) {
+        const int gidx = tid + e * NTHREADS;
+        const int nB = gidx % BN, kq = gidx / BN;
+        const int ng = n0 + nB;
+        const bool n_ok = ng < Ncls && kq < KT / 4;
+        int bb = 0, iy0 = 0, ix0 = 0;
+        if (n_ok) {
+            bb = ng / (c.OH * c.OW);
+            const int r = ng % (c.OH * c.OW);
+            iy0 = (r / c.OW) * d.is;
+            ix0 = (r % c.OW) * d.is;
+        }
+        dchB[e] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = kq * 4 + j;
+            const int dch = k / T, t = k - dch * T;
+            const int tb = stab[t];
+            const int iy = iy0 + (tb & 0xff) - 8, ix = ix0 + ((tb >> 8) & 0xff) - 8;
+            const bool ok = n_ok & (iy >= 0) & (iy < d.H) & (ix >= 0) & (ix < d.W);
+            offB[e][j] = ok ? (((bb * d.Cr + dch) * d.H + iy) * d.W + ix) * 4 : OOB;
+            offS[e][j] = (SCALE && n_ok) ? (bb * d.Cr + dch) * 4 : OOB;
+            dchB[e] |= (unsigned)dch << (8 * j);
+        }
+    }
+    // ---- weight groups: k fastest (contiguous taps of the forward layout): k4 = gidx % (KT/4), m = gidx / (KT/4)
+    int offA[GA][4];
+    unsigned dchA[GA];
+#pragma unroll
+    for (int e = 0; e < GA; e++) {
+        const int gidx = tid + e * NTHREADS;
+        const int kq = gidx % (KT / 4), m = gidx / (KT / 4);
+        const bool ok = m < BM && m0 + m < d.M;
+        dchA[e] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = kq * 4 + j;
+            const int dch = k / T, t = k - dch * T;
+            offA[e][j] = ok ? ((m0 + m) * d.w_ms + dch * d.w_ks + (stab[t] >> 16)) * 4 : OOB;
+            dchA[e] |= (unsigned)dch << (8 * j);
+        }
+    }
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; i++)
+#pragma unroll
+        for (int j = 0; j < WNT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    for (int kt = kt_begin; kt < kt_end; kt++) {
+        const int ch0 = kt * CPT, left = d.Cr - ch0;    // channels left (partial last tile)
+        // gather + convert + write
+#pragma unroll
+        for (int e = 0; e < GB; e++) {
+            const int gidx = tid + e * NTHREADS;
+            if (gidx >= BN * (KT / 4)) break;
+            f16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool out = (int)((dchB[e] >> (8 * j)) & 0xff) >= left;
+                float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, out ? OOB : offB[e][j], ch0 * HW * 4, 0));
+                if constexpr (SCALE)
+                    v *= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, out ? OOB : offS[e][j], ch0 * 4, 0));
+                h[j] = (_Float16)v;
+            }
+            *reinterpret_cast<f16x4 *>(&Bs[(gidx % BN) * KTP + (gidx / BN) * 4]) = h;
+        }
+#pragma unroll
+        for (int e = 0; e < GA; e++) {
+            const int gidx = tid + e * NTHREADS;
+            if (gidx >= BM * (KT / 4)) break;
+            f16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool out = (int)((dchA[e] >> (8 * j)) & 0xff) >= left;
+                h[j] = (_Float16)__uint_as_float(
+                    __builtin_amdgcn_raw_buffer_load_b32(rw, out ? OOB : offA[e][j], ch0 * d.w_ks * 4, 0));
+            }
+            *reinterpret_cast<f16x4 *>(&As[(gidx / (KT / 4)) * KTP + (gidx % (KT / 4)) * 4]) = h;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KT / 8; ks++) {
+            f16x4 a[WMT], b[WNT];
+#pragma unroll
+            for (int i = 0; i < WMT; i++)
+                a[i] = *reinterpret_cast<const f16x4 *>(&As[(wm * (BM / 2) + i * 32 + l31) * KTP + ks * 8 + lk * 4]);
+#pragma unroll
+            for (int j = 0; j < WNT; j++)
+                b[j] = *reinterpret_cast<const f16x4 *>(&Bs[(wn * (BN / 2) + j * 32 + l31) * KTP + ks * 8 + lk * 4]);
+#pragma unroll
+            for (int i = 0; i < WMT; i++)
+#pragma unroll
+                for (int j = 0; j < WNT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (as the fp32 kernel): C[m][n], m = (r&3) + 8*(r>>2) + 4*(lane>>5), n = lane&31
+#pragma unroll
+    for (int j = 0; j < WNT; j++) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+        if (n >= Ncls) continue;
+        const int b = n / (c.OH * c.OW);
+        const int r_ = n % (c.OH * c.OW);
+        const int oy = (r_ / c.OW) * d.os + c.oy0, ox = (r_ % c.OW) * d.os + c.ox0;
+        float *yb = d.y + ((size_t)b * d.M * d.OHf + oy) * d.OWf + ox;
+        const float *ob = d.out_scale ? d.out_scale + (size_t)b * d.M : nullptr;
+#pragma unroll
+        for (int i = 0; i < WMT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= d.M) continue;
+                float v = acc[i][j][r];
+                if (ob) v *= ob[m];
+                if (d.bias) v += d.bias[m];
+                if (d.act) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
+                float *dst = yb + (size_t)m * d.OHf * d.OWf;
+                if (d.splitk > 1) unsafeAtomicAdd(dst, v);
+                else *dst = v;
+            }
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(NTHREADS) void modconv_f16_kernel(ConvDesc d) {
+    constexpr int KTP = 72 + 4;
+    __shared__ __attribute__((aligned(16))) _Float16 As[BM * KTP];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[BN * KTP];
+    __shared__ int stab[25];
+    const ConvClass &c = d.cls[blockIdx.z];
+    const int tiles_m = (d.M + BM - 1) / BM;
+    const int tile_id = xcd_logical_tile();
+    if ((int)(tile_id / tiles_m) * BN >= d.B * c.OH * c.OW) return;
+    const int cpt = c.T == 9 ? 8 : c.T == 4 ? 8 : c.T == 2 ? 16 : 32;
+    const int ktiles = (d.Cr + cpt - 1) / cpt;
+    const int per = (ktiles + d.splitk - 1) / d.splitk;
+    if ((int)blockIdx.y * per >= ktiles) return;
+    if (threadIdx.x < 25) stab[threadIdx.x] = c.tab[threadIdx.x];
+    __syncthreads();
+    const bool scale = d.in_scale != nullptr;
+    switch (c.T) {
+    case 9:
+        if (scale) modconv_f16_body<BM, BN, 9, true>(d, c, As, Bs, stab, tile_id);
+        else modconv_f16_body<BM, BN, 9, false>(d, c, As, Bs, stab, tile_id);
+        break;
+    case 4:
+        if (scale) modconv_f16_body<BM, BN, 4, true>(d, c, As, Bs, stab, tile_id);
+        else modconv_f16_body<BM, BN, 4, false>(d, c, As, Bs, stab, tile_id);
+        break;
+    case 2:
+        if (scale) modconv_f16_body<BM, BN, 2, true>(d, c, As, Bs, stab, tile_id);
+        else modconv_f16_body<BM, BN, 2, false>(d, c, As, Bs, stab, tile_id);
+        break;
+    default:
+        if (scale) modconv_f16_body<BM, BN, 1, true>(d, c, As, Bs, stab, tile_id);
+        else modconv_f16_body<BM, BN, 1, false>(d, c, As, Bs, stab, tile_id);
+        break;
+    }
+}
+
 static int pack(int dy, int dx, int wt) { return (dy + 8) | ((dx + 8) << 8) | (wt << 16); }
 
 }  // namespace g2s
@@ -416,7 +625,7 @@ struct ConvGeom {
 static int conv_launch(const float *x, const float *w, const float *in_scale, const float *out_scale,
                        const float *bias, int act, float act_alpha, float act_gain, float *y, int B,
                        int Cr, int M, int H, int W, const ConvGeom &g, int tuned_tile, int tuned_splitk,
-                       g2s_stream_t stream, bool y_is_zero = false) {
+                       g2s_stream_t stream, bool y_is_zero = false, bool f16_operands = false) {
     G2S_REQUIRE(x && w && y, "x, w, y must not be NULL");
     G2S_REQUIRE(B > 0 && Cr > 0 && M > 0 && H > 0 && W > 0, "sizes must be positive");
     const int k = g.k, s_ = g.stride, p_ = g.pad, KK = k * k;
@@ -534,7 +743,13 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
     }
     dim3 grid(tiles, splitk, d.ncls);
-    if (big) {
+    if (f16_operands) {
+        for (int i = 0; i < d.ncls; i++)
+            G2S_REQUIRE(d.cls[i].T == 1 || d.cls[i].T == 2 || d.cls[i].T == 4 || d.cls[i].T == 9,
+                        "fp16 operands: 1x1 / 3x3 kernels (stride 1 or 2) only");
+        if (pick == 2) modconv_f16_kernel<64, 64><<<grid, NTHREADS, 0, st>>>(d);
+        else modconv_f16_kernel<128, 128><<<grid, NTHREADS, 0, st>>>(d);
+    } else if (big) {
         if (pick == 0) modconv_kernel<128, 128, 26><<<grid, NTHREADS, 0, st>>>(d);
         else if (pick == 1) modconv_kernel<128, 64, 26><<<grid, NTHREADS, 0, st>>>(d);
         else modconv_kernel<64, 64, 26><<<grid, NTHREADS, 0, st>>>(d);
@@ -554,7 +769,7 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
 static int modconv_launch(const float *x, const float *w, const float *in_scale,
                           const float *out_scale, const float *bias, int act, float act_alpha,
                           float act_gain, float *y, int B, int Cin, int Cout, int H, int W, int k,
-                          int mode, int transpose, g2s_stream_t stream) {
+                          int mode, int transpose, g2s_stream_t stream, bool f16_operands = false) {
     G2S_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "sizes must be positive");
     G2S_REQUIRE(k == 1 || k == 3, "kernel size must be 1 or 3 (got %d)", k);
     G2S_REQUIRE(mode == G2S_CONV_PLAIN || mode == G2S_CONV_UP2 || mode == G2S_CONV_DOWN2,
@@ -569,7 +784,7 @@ static int modconv_launch(const float *x, const float *w, const float *in_scale,
     g.m_major = !transpose;
     if (!g.adjoint && mode != G2S_CONV_PLAIN) G2S_REQUIRE(H >= k && W >= k, "input smaller than the kernel");
     int tile = -1, splitk = -1;
-    if (H == W)
+    if (H == W && !f16_operands)
         for (const TunedConv *t = kTuned; t->B; ++t)
             if (t->B == B && t->Cin == Cin && t->Cout == Cout && t->H == H && t->k == k && t->mode == mode &&
                 t->transpose == transpose && t->fused == (bias != nullptr || act != 0)) {
@@ -578,7 +793,16 @@ static int modconv_launch(const float *x, const float *w, const float *in_scale,
                 break;
             }
     return conv_launch(x, w, in_scale, out_scale, bias, act, act_alpha, act_gain, y, B,
-                       transpose ? Cout : Cin, transpose ? Cin : Cout, H, W, g, tile, splitk, stream);
+                       transpose ? Cout : Cin, transpose ? Cin : Cout, H, W, g, tile, splitk, stream, false,
+                       f16_operands);
+}
+
+extern "C" int g2s_modconv_f16(const float *x, const float *w, const float *in_scale, const float *out_scale,
+                               const float *bias, float *y, int B, int Cin, int Cout, int H, int W, int k,
+                               int mode, int transpose, int act, float alpha, float gain, g2s_stream_t stream) {
+    G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
+    return modconv_launch(x, w, in_scale, out_scale, bias, act, alpha, gain, y, B, Cin, Cout, H, W, k, mode,
+                          transpose, stream, true);
 }
 
 extern "C" int g2s_modconv(const float *x, const float *w, const float *in_scale,

@@ -62,6 +62,13 @@ class GAN2Shape(nn.Module):
 
         self.image_size = config.get('image_size')
         self.collected = None
+        # BASELINE config 5: fp16 operands / fp32 accumulation for the frozen G / D / VGG GEMMs (a
+        # process-wide switch of modconv.py; absent = the reference's fp32 arithmetic)
+        if config.get('mfma_operands') is not None:
+            from . import modconv as _mc
+            if config['mfma_operands'] not in ('f32', 'f16'):
+                raise ValueError("mfma_operands must be 'f32' or 'f16'")
+            _mc.OPERANDS = config['mfma_operands']
 
         self.lighting_net = networks.LightingNet(self.image_size, self.debug).to(self.device)
         self.viewpoint_net = networks.ViewpointNet(self.image_size, self.debug).to(self.device)

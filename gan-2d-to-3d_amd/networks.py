@@ -59,19 +59,27 @@ def run_fused(mods, x):
 
 
 class Encoder(nn.Module):
-    """ViewpointNet / LightingNet trunk (networks.py:23-50)."""
+    """ViewpointNet / LightingNet trunk (networks.py:23-50): stride-2 convolutions down to 4x4, a
+    4x4 convolution to 1x1, a 1x1 head.  The reference hard-codes FIVE stride-2 layers, i.e.
+    image_size 128 (any other size leaves no 1x1 map); here their number follows the size — log2(size)
+    - 2, widths nf * 2^i capped at nf * 16 — which is the reference's network at 128 (same state
+    dict) and extends it to the 64x64 / 256x256 configs (BASELINE configs 1 and 5)."""
 
     def __init__(self, cin, cout, size):
         super().__init__()
+        if size < 16 or size & (size - 1):
+            raise ValueError("image_size must be a power of two >= 16")
         nf = max(4096 // size, 16)
-        chans = [cin, nf, nf * 2, nf * 4, nf * 8, nf * 16]
+        downs = size.bit_length() - 3          # log2(size) - 2
+        chans = [cin] + [min(nf * 2 ** i, nf * 16) for i in range(downs)]
         layers = []
         for a, b in zip(chans[:-1], chans[1:]):
             layers += [nn.Conv2d(a, b, kernel_size=4, stride=2, padding=1, bias=False),
                        nn.ReLU(inplace=True)]
-        layers += [nn.Conv2d(nf * 16, nf * 16, kernel_size=4, stride=1, padding=0, bias=False),
+        top = chans[-1]
+        layers += [nn.Conv2d(top, top, kernel_size=4, stride=1, padding=0, bias=False),
                    nn.ReLU(inplace=True),
-                   nn.Conv2d(nf * 16, cout, kernel_size=1, stride=1, padding=0, bias=False),
+                   nn.Conv2d(top, cout, kernel_size=1, stride=1, padding=0, bias=False),
                    nn.Tanh()]
         self.network = nn.Sequential(*layers)
 
@@ -168,13 +176,17 @@ class OffsetEncoder(nn.Module):
 
     def __init__(self, image_size=128, cin=3, cout=512, activation=None, debug=False):
         super().__init__()
-        assert image_size in [64, 128]
+        # the reference asserts image_size in [64, 128] (networks.py:205-206); 256 is this package's
+        # extension for BASELINE config 5: one more ResBlock (8x8 -> 4x4) at constant width
+        assert image_size in [64, 128, 256]
         nf = 16
         network = [nn.Conv2d(cin, 2 * nf, kernel_size=4, stride=2, padding=1), nn.ReLU(),
                    ResBlock(2 * nf, 4 * nf), ResBlock(4 * nf, 8 * nf), ResBlock(8 * nf, 16 * nf)]
-        if image_size == 128:
-            network += [ResBlock(16 * nf, 32 * nf),
-                        nn.Conv2d(32 * nf, 64 * nf, kernel_size=4, stride=1, padding=0), nn.ReLU(),
+        if image_size >= 128:
+            network += [ResBlock(16 * nf, 32 * nf)]
+            if image_size == 256:
+                network += [ResBlock(32 * nf, 32 * nf)]
+            network += [nn.Conv2d(32 * nf, 64 * nf, kernel_size=4, stride=1, padding=0), nn.ReLU(),
                         nn.Conv2d(64 * nf, cout, kernel_size=1, stride=1, padding=0)]
         else:
             network += [nn.Conv2d(16 * nf, 32 * nf, kernel_size=4, stride=1, padding=0), nn.ReLU(),

@@ -192,6 +192,15 @@ int g2s_conv2d(const float *x, const float *w, const float *bias, float *y, int 
 int g2s_conv2d_wgrad(const float *A, const float *G, float *dw, int B, int Ca, int Cg, int PH, int PW,
                      int GH, int GW, int k, int stride, int pad, int dw_is_zero, g2s_stream_t stream);
 
+/* fp16-OPERAND form of g2s_modconv / g2s_conv_bias_act (BASELINE config 5, "fp16 MFMA path"): same
+ * arguments and geometry; x, w, y stay fp32 in memory, both GEMM operands are rounded to fp16 on
+ * their way into LDS and multiplied by v_mfma_f32_32x32x8_f16 with fp32 accumulation.  bias (NULL ok)
+ * and act (0 none / 1 leaky-ReLU(alpha) * gain) form the epilogue.  1x1 and 3x3 kernels only.
+ * Results differ from the fp32 kernels at the 1e-3 level (fp16 rounding of the operands). */
+int g2s_modconv_f16(const float *x, const float *w, const float *in_scale, const float *out_scale,
+                    const float *bias, float *y, int B, int Cin, int Cout, int H, int W, int k, int mode,
+                    int transpose, int act, float alpha, float gain, g2s_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * 3x3 stride-1 convolution (padding 1) as Winograd F(2x2, 3x3) on the fp32 matrix cores
  * (csrc/winograd.hip): the same map as g2s_modconv(mode = G2S_CONV_PLAIN, k = 3) — the generator's

@@ -223,3 +223,37 @@ def test_winograd_weights_follow_the_tensor_version(L):
         torch.testing.assert_close(mc.modconv_raw(x, w, None, None, PLAIN, 0), y1, rtol=1e-4, atol=1e-4)
     finally:
         mc.WINOGRAD, mc.WINO_FORCE = saved
+
+
+# ----------------------------------------------------------------------------- fp16 operands (config 5)
+@pytest.mark.parametrize("transpose", [0, 1])
+@pytest.mark.parametrize("B,cin,cout,H,k,mode", [
+    (4, 128, 128, 64, 3, PLAIN), (2, 512, 512, 16, 3, PLAIN), (2, 256, 128, 32, 3, UP2), (2, 128, 256, 33, 3, DOWN2),
+    (2, 128, 3, 64, 1, PLAIN), (3, 70, 50, 19, 3, PLAIN), (2, 40, 24, 9, 3, UP2), (2, 3, 64, 32, 3, PLAIN)])
+def test_modconv_f16_operands_vs_oracle(L, B, cin, cout, H, k, mode, transpose):
+    """g2s_modconv_f16 (fp16 operands, fp32 accumulation — BASELINE config 5) against the fp32
+    oracle: the operand rounding (2^-11 relative, random sign) leaves ~1e-3 of the output scale after
+    K = Cin k^2 terms; bound: 4e-3 of the rms output elementwise."""
+    from gan2shape_amd import modconv as mc
+    rng = np.random.default_rng(B + cin + cout + H + mode + transpose)
+    w = (rng.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+    if transpose:
+        oh = {PLAIN: H, UP2: (H - 1) * 2 + k, DOWN2: (H - k) // 2 + 1}[mode]
+        x = rng.standard_normal((B, cout, oh, oh)).astype(np.float32)
+        s_in, s_out = (1 + 0.3 * rng.standard_normal((B, cout))).astype(np.float32), None
+    else:
+        x = rng.standard_normal((B, cin, H, H)).astype(np.float32)
+        s_in = (1 + 0.3 * rng.standard_normal((B, cin))).astype(np.float32)
+        s_out = (1 + 0.3 * rng.standard_normal((B, cout))).astype(np.float32)
+    exp = expected_modconv(x, w, s_in, s_out, mode, transpose)
+    saved = mc.OPERANDS
+    try:
+        mc.OPERANDS = "f16"
+        y = mc.modconv_raw(dev(x), dev(w), dev(s_in), None if s_out is None else dev(s_out), mode, transpose)
+    finally:
+        mc.OPERANDS = saved
+    got = y.cpu().numpy()
+    assert got.shape == exp.shape
+    rms = float(np.sqrt((exp.astype(np.float64) ** 2).mean()))
+    assert np.abs(got - exp).max() <= 4e-3 * rms, (np.abs(got - exp).max(), rms)
+    assert np.linalg.norm(got - exp) <= 1e-3 * np.linalg.norm(exp)

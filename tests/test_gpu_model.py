@@ -621,3 +621,44 @@ def test_bench_self_launches_ranks():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0
     assert line["scaling"] == "weak" and line["cpu_baseline"] is None
+
+
+def test_config5_fp16_operands_and_256():
+    """BASELINE config 5 (256x256 face, confidence-map prior, fp16-operand MFMA): (a) the generator
+    with fp16 operands stays within 1e-2 of its fp32 output, latent gradient within
+    2e-2 (L2); (b) the 256x256 model — extended V / L / E nets, confidence prior from a synthetic soft
+    mask — runs prior pre-training and one iteration of each kind with finite losses."""
+    import bench
+    from gan2shape_amd import modconv as mc
+    from gan2shape_amd import stylegan2 as sg2
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import Trainer
+    G = sg2.Generator(128, 512, 8, channel_multiplier=1)
+    fill_deterministic(G, 77)
+    G = G.cuda().eval().requires_grad_(False)
+    torch.manual_seed(0)
+    w = (0.5 * torch.randn(4, 512, device="cuda")).requires_grad_(True)
+    out = {}
+    saved = mc.OPERANDS
+    try:
+        for mode in ("f32", "f16"):
+            mc.OPERANDS = mode
+            img, _ = G([w], input_is_w=True, randomize_noise=False)
+            (gw,) = torch.autograd.grad(img, w, torch.ones_like(img))
+            out[mode] = (img.detach(), gw)
+        scale = float(out["f32"][0].abs().max())
+        assert float((out["f16"][0] - out["f32"][0]).abs().max()) <= 1e-2 * scale
+        assert float((out["f16"][1] - out["f32"][1]).norm()) <= 2e-2 * float(out["f32"][1].norm())
+        assert float((out["f16"][0] - out["f32"][0]).abs().max()) > 0          # the fp16 path did run
+        # (b) the 256x256 configuration
+        cfg = bench.face_config(n_proj=2, workload="face256_fp16")
+        cfg.update(n_epochs_prior=1)
+        torch.manual_seed(0)
+        t = Trainer(GAN2Shape, cfg, device=torch.device("cuda"))
+        assert mc.OPERANDS == "f16" and t.model.image_size == 256
+        image, latent = bench.synthetic_sample(t.model, 3, torch.device("cuda"))
+        assert tuple(image.shape) == (1, 3, 256, 256)
+        n = t.fit([(image[0].cpu(), latent[0].cpu(), 0)], stages=[{'step1': 1, 'step2': 1, 'step3': 1}])
+        assert n == 3 and all(math.isfinite(h[3]) for h in t.history)
+    finally:
+        mc.OPERANDS = saved
