@@ -27,6 +27,8 @@ struct WgradParams {
     int ktiles;  // ceil(K / 32)
     int per;     // K tiles per blockIdx.y slice
     int atomic;  // more than one slice
+    int groups;  // independent problems (blockIdx.z): A has groups * Ca channels per sample, G has
+                 // groups * Cg, dw holds the groups back to back (op/conv.py PairConvFunction)
 };
 
 __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgradParams p) {
@@ -38,6 +40,8 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgradParams p) {
     const int m0 = (blockIdx.x % tiles_m) * WG_BM, n0 = (blockIdx.x / tiles_m) * WG_BN;
     const int kt0 = blockIdx.y * p.per, kt1 = min(p.ktiles, kt0 + p.per);
     const int P = p.PH * p.PW, KK = p.k * p.k;
+    const int grp = blockIdx.z;
+    const int Ca_tot = p.Ca * p.groups, Cg_tot = p.Cg * p.groups;
 
     // this thread's elements: pixel lane kl fixed, rows (a or n) r0 + 8 e
     const int kl = tid & 31, r0 = tid >> 5;
@@ -59,8 +63,8 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgradParams p) {
         const bool kok = kg < p.K;
         const int b = kok ? kg / P : 0, pix = kok ? kg - b * P : 0;
         const int py = pix / p.PW, px = pix - py * p.PW;
-        const float *ap = p.A + ((size_t)b * p.Ca + m0 + r0) * P + pix;
-        const float *gp = p.G + (size_t)b * p.Cg * p.GH * p.GW;
+        const float *ap = p.A + ((size_t)b * Ca_tot + grp * p.Ca + m0 + r0) * P + pix;
+        const float *gp = p.G + ((size_t)b * Cg_tot + grp * p.Cg) * p.GH * p.GW;
         const int gy0 = py * p.stride, gx0 = px * p.stride;
 #pragma unroll
         for (int e = 0; e < WG_E; e++) {
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgradParams p) {
     for (int r = 0; r < 16; r++) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (m >= p.Ca) continue;
-        float *dst = p.dw + (size_t)m * p.N + n;
+        float *dst = p.dw + ((size_t)grp * p.Ca + m) * p.N + n;
         if (p.atomic) unsafeAtomicAdd(dst, acc[r]);
         else *dst = acc[r];
     }
@@ -107,15 +111,15 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgradParams p) {
 
 using namespace g2s;
 
-extern "C" int g2s_conv2d_wgrad(const float *A, const float *G, float *dw, int B, int Ca, int Cg,
-                                int PH, int PW, int GH, int GW, int k, int stride, int pad,
-                                int dw_is_zero, g2s_stream_t stream) {
+static int wgrad_impl(const float *A, const float *G, float *dw, int B, int Ca, int Cg, int PH, int PW, int GH,
+                      int GW, int k, int stride, int pad, int dw_is_zero, int groups, g2s_stream_t stream) {
     G2S_REQUIRE(A && G && dw, "NULL pointer argument");
     G2S_REQUIRE(B > 0 && Ca > 0 && Cg > 0 && PH > 0 && PW > 0 && GH > 0 && GW > 0, "sizes must be positive");
     G2S_REQUIRE(k >= 1 && k <= 5 && (stride == 1 || stride == 2) && pad >= 0 && pad < k,
                 "k must be 1..5, stride 1 or 2, 0 <= pad < k");
-    G2S_REQUIRE((long)B * Cg * GH * GW < (1l << 31) && (long)B * Ca * PH * PW < (1l << 31) &&
-                    (long)Ca * Cg * k * k < (1l << 31), "tensor too large");
+    G2S_REQUIRE(groups >= 1 && groups <= 8, "groups must be 1..8");
+    G2S_REQUIRE((long)B * groups * Cg * GH * GW < (1l << 31) && (long)B * groups * Ca * PH * PW < (1l << 31) &&
+                    (long)groups * Ca * Cg * k * k < (1l << 31), "tensor too large");
     WgradParams p{};
     p.A = A;
     p.G = G;
@@ -130,17 +134,31 @@ extern "C" int g2s_conv2d_wgrad(const float *A, const float *G, float *dw, int B
     p.k = k;
     p.stride = stride;
     p.pad = pad;
+    p.groups = groups;
     p.N = Cg * k * k;
     p.K = B * PH * PW;
     p.ktiles = cdiv(p.K, WG_BK);
     const int tiles = cdiv(Ca, WG_BM) * cdiv(p.N, WG_BN);
-    int split = std::max(1, std::min(p.ktiles, cdiv(768, tiles)));
+    int split = std::max(1, std::min(p.ktiles, cdiv(768, tiles * groups)));
     p.per = cdiv(p.ktiles, split);
     split = cdiv(p.ktiles, p.per);
     p.atomic = split > 1;
     hipStream_t st = as_stream(stream);
-    if (p.atomic && !dw_is_zero && hipMemsetAsync(dw, 0, (size_t)Ca * p.N * sizeof(float), st) != hipSuccess)
+    if (p.atomic && !dw_is_zero &&
+        hipMemsetAsync(dw, 0, (size_t)groups * Ca * p.N * sizeof(float), st) != hipSuccess)
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(dw) failed");
-    conv_wgrad_kernel<<<dim3(tiles, split), WG_THREADS, 0, st>>>(p);
+    conv_wgrad_kernel<<<dim3(tiles, split, groups), WG_THREADS, 0, st>>>(p);
     return check_launch("g2s_conv2d_wgrad");
+}
+
+extern "C" int g2s_conv2d_wgrad(const float *A, const float *G, float *dw, int B, int Ca, int Cg,
+                                int PH, int PW, int GH, int GW, int k, int stride, int pad,
+                                int dw_is_zero, g2s_stream_t stream) {
+    return wgrad_impl(A, G, dw, B, Ca, Cg, PH, PW, GH, GW, k, stride, pad, dw_is_zero, 1, stream);
+}
+
+extern "C" int g2s_conv2d_wgrad_grouped(const float *A, const float *G, float *dw, int B, int Ca, int Cg,
+                                        int PH, int PW, int GH, int GW, int k, int stride, int pad,
+                                        int dw_is_zero, int groups, g2s_stream_t stream) {
+    return wgrad_impl(A, G, dw, B, Ca, Cg, PH, PW, GH, GW, k, stride, pad, dw_is_zero, groups, stream);
 }

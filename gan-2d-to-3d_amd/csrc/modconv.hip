@@ -47,7 +47,12 @@ struct ConvDesc {
     int os;              // output stride of a class (1, or 2 for the polyphase classes)
     int ncls;
     int splitk;
-    int w_bytes;         // size of w in bytes (buffer-resource range)
+    int w_bytes;         // size of ONE group's w in bytes (buffer-resource range)
+    // Grouped launch (two structurally identical trained nets run as one, their channels side by
+    // side: op/conv.py PairConvFunction): `groups` independent convolutions of Cr -> M channels;
+    // x has Cx = groups * Cr channels per sample, y has My = groups * M, w / bias hold the groups
+    // back to back.  groups = 1: Cx = Cr, My = M.
+    int groups, Cx, My;
     const float *bias;   // [M] added after out_scale, or NULL
     int act;             // 0: none, 1: leaky-ReLU(alpha) * gain applied after the bias
     float act_alpha, act_gain;
@@ -74,7 +79,7 @@ template <int BM, int BN, int T, bool PARTIAL, bool SCALE>
 __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass &c,
                                              float (&As)[2][KTile<T>::KMAX][BM + 1],
                                              float (&Bs)[2][KTile<T>::KMAX + 1][BN],
-                                             const int (&stab)[25], const int tile_id) {
+                                             const int (&stab)[25], const int tile_id, const int grp) {
     constexpr int BKT = KTile<T>::BKT, CPT = KTile<T>::CPT, BK_MAX = KTile<T>::KMAX;
     constexpr int WMT = BM / 64, WNT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
     constexpr bool WIDE = (T == 9);              // 9 contiguous taps per (m, channel): 3 x dwordx3
@@ -96,8 +101,9 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
     // Buffer resources (SGPR descriptors built from kernel arguments only): 32-bit per-lane byte
     // offsets that stay CONSTANT over the K loop + a scalar offset for the channel base; the
     // hardware range check zeroes masked elements, so the K loop carries no address arithmetic.
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, d.B * d.Cr * HW * 4, 0x00020000);
-    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)d.w, 0, d.w_bytes, 0x00020000);
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)(d.x + (size_t)grp * d.Cr * HW), 0,
+                                                      (d.B * d.Cx - grp * d.Cr) * HW * 4, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)(d.w + (size_t)grp * (d.w_bytes / 4)), 0, d.w_bytes, 0x00020000);
     const auto rsc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(SCALE ? d.in_scale : d.w), 0, SCALE ? d.B * d.Cr * 4 : 4, 0x00020000);
 
@@ -120,7 +126,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
         const int tb = stab[t < T ? t : 0];
         const int iy = iy0 + (tb & 0xff) - 8, ix = ix0 + ((tb >> 8) & 0xff) - 8;
         const bool ok = n_ok && k < BKT && dch < CPT && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
-        offB[e] = ok ? (((bb * d.Cr + dch) * d.H + iy) * d.W + ix) * 4 : OOB;
+        offB[e] = ok ? (((bb * d.Cx + dch) * d.H + iy) * d.W + ix) * 4 : OOB;
         dchB[e] = dch;
     }
     const int offS = n_ok ? bb * d.Cr * 4 : OOB;  // + channel * 4
@@ -287,8 +293,9 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
         const int b = n / (c.OH * c.OW);
         const int r_ = n % (c.OH * c.OW);
         const int oy = (r_ / c.OW) * d.os + c.oy0, ox = (r_ % c.OW) * d.os + c.ox0;
-        float *yb = d.y + ((size_t)b * d.M * d.OHf + oy) * d.OWf + ox;
+        float *yb = d.y + (((size_t)b * d.My + grp * d.M) * d.OHf + oy) * d.OWf + ox;
         const float *ob = d.out_scale ? d.out_scale + (size_t)b * d.M : nullptr;
+        const float *gbias = d.bias ? d.bias + grp * d.M : nullptr;
 #pragma unroll
         for (int i = 0; i < WMT; i++)
 #pragma unroll
@@ -297,7 +304,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
                 if (m >= d.M) continue;
                 float v = acc[i][j][r];
                 if (ob) v *= ob[m];
-                if (d.bias) v += d.bias[m];
+                if (gbias) v += gbias[m];
                 if (d.act) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
                 float *dst = yb + (size_t)m * d.OHf * d.OWf;
                 if (d.splitk > 1) unsafeAtomicAdd(dst, v);
@@ -319,7 +326,12 @@ __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
     const ConvClass &c = d.cls[blockIdx.z];
     // uniform early exits: smaller parity classes need fewer tiles; empty split-K slices
     const int tiles_m = (d.M + BM - 1) / BM;
-    const int tile_id = xcd_logical_tile();
+    // grouped launch: the groups' m-tiles follow each other within a pixel tile (they read
+    // neighbouring channels of the same pixels)
+    const int tile_all = xcd_logical_tile();
+    const int mt_all = tile_all % (tiles_m * d.groups);
+    const int grp = mt_all / tiles_m;
+    const int tile_id = (tile_all / (tiles_m * d.groups)) * tiles_m + mt_all % tiles_m;
     if ((int)(tile_id / tiles_m) * BN >= d.B * c.OH * c.OW) return;
     const int ktiles = ktiles_of(d.Cr, c.T);
     const int per = (ktiles + d.splitk - 1) / d.splitk;
@@ -328,47 +340,47 @@ __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
     __syncthreads();
     const bool scale = d.in_scale != nullptr;
     if constexpr (KMAX == 26) {  // 5x5 (never modulated)
-        modconv_body<BM, BN, 25, true, false>(d, c, As, Bs, stab, tile_id);
+        modconv_body<BM, BN, 25, true, false>(d, c, As, Bs, stab, tile_id, grp);
         return;
     } else
     switch (c.T) {  // compile-time tap count; no partial-tile checks when the channels fill the K tiles
     case 9:
         if (d.Cr % 2) {
-            if (scale) modconv_body<BM, BN, 9, true, true>(d, c, As, Bs, stab, tile_id);
-            else modconv_body<BM, BN, 9, true, false>(d, c, As, Bs, stab, tile_id);
+            if (scale) modconv_body<BM, BN, 9, true, true>(d, c, As, Bs, stab, tile_id, grp);
+            else modconv_body<BM, BN, 9, true, false>(d, c, As, Bs, stab, tile_id, grp);
         } else {
-            if (scale) modconv_body<BM, BN, 9, false, true>(d, c, As, Bs, stab, tile_id);
-            else modconv_body<BM, BN, 9, false, false>(d, c, As, Bs, stab, tile_id);
+            if (scale) modconv_body<BM, BN, 9, false, true>(d, c, As, Bs, stab, tile_id, grp);
+            else modconv_body<BM, BN, 9, false, false>(d, c, As, Bs, stab, tile_id, grp);
         }
         break;
     case 16:  // 4x4 (never modulated)
-        modconv_body<BM, BN, 16, true, false>(d, c, As, Bs, stab, tile_id);
+        modconv_body<BM, BN, 16, true, false>(d, c, As, Bs, stab, tile_id, grp);
         break;
     case 4:
         if (d.Cr % 4) {
-            if (scale) modconv_body<BM, BN, 4, true, true>(d, c, As, Bs, stab, tile_id);
-            else modconv_body<BM, BN, 4, true, false>(d, c, As, Bs, stab, tile_id);
+            if (scale) modconv_body<BM, BN, 4, true, true>(d, c, As, Bs, stab, tile_id, grp);
+            else modconv_body<BM, BN, 4, true, false>(d, c, As, Bs, stab, tile_id, grp);
         } else {
-            if (scale) modconv_body<BM, BN, 4, false, true>(d, c, As, Bs, stab, tile_id);
-            else modconv_body<BM, BN, 4, false, false>(d, c, As, Bs, stab, tile_id);
+            if (scale) modconv_body<BM, BN, 4, false, true>(d, c, As, Bs, stab, tile_id, grp);
+            else modconv_body<BM, BN, 4, false, false>(d, c, As, Bs, stab, tile_id, grp);
         }
         break;
     case 2:
         if (d.Cr % 8) {
-            if (scale) modconv_body<BM, BN, 2, true, true>(d, c, As, Bs, stab, tile_id);
-            else modconv_body<BM, BN, 2, true, false>(d, c, As, Bs, stab, tile_id);
+            if (scale) modconv_body<BM, BN, 2, true, true>(d, c, As, Bs, stab, tile_id, grp);
+            else modconv_body<BM, BN, 2, true, false>(d, c, As, Bs, stab, tile_id, grp);
         } else {
-            if (scale) modconv_body<BM, BN, 2, false, true>(d, c, As, Bs, stab, tile_id);
-            else modconv_body<BM, BN, 2, false, false>(d, c, As, Bs, stab, tile_id);
+            if (scale) modconv_body<BM, BN, 2, false, true>(d, c, As, Bs, stab, tile_id, grp);
+            else modconv_body<BM, BN, 2, false, false>(d, c, As, Bs, stab, tile_id, grp);
         }
         break;
     default:
         if (d.Cr % 16) {
-            if (scale) modconv_body<BM, BN, 1, true, true>(d, c, As, Bs, stab, tile_id);
-            else modconv_body<BM, BN, 1, true, false>(d, c, As, Bs, stab, tile_id);
+            if (scale) modconv_body<BM, BN, 1, true, true>(d, c, As, Bs, stab, tile_id, grp);
+            else modconv_body<BM, BN, 1, true, false>(d, c, As, Bs, stab, tile_id, grp);
         } else {
-            if (scale) modconv_body<BM, BN, 1, false, true>(d, c, As, Bs, stab, tile_id);
-            else modconv_body<BM, BN, 1, false, false>(d, c, As, Bs, stab, tile_id);
+            if (scale) modconv_body<BM, BN, 1, false, true>(d, c, As, Bs, stab, tile_id, grp);
+            else modconv_body<BM, BN, 1, false, false>(d, c, As, Bs, stab, tile_id, grp);
         }
         break;
     }
@@ -625,7 +637,7 @@ struct ConvGeom {
 static int conv_launch(const float *x, const float *w, const float *in_scale, const float *out_scale,
                        const float *bias, int act, float act_alpha, float act_gain, float *y, int B,
                        int Cr, int M, int H, int W, const ConvGeom &g, int tuned_tile, int tuned_splitk,
-                       g2s_stream_t stream, bool y_is_zero = false, bool f16_operands = false) {
+                       g2s_stream_t stream, bool y_is_zero = false, bool f16_operands = false, int groups = 1) {
     G2S_REQUIRE(x && w && y, "x, w, y must not be NULL");
     G2S_REQUIRE(B > 0 && Cr > 0 && M > 0 && H > 0 && W > 0, "sizes must be positive");
     const int k = g.k, s_ = g.stride, p_ = g.pad, KK = k * k;
@@ -650,6 +662,11 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
     d.w_ms = g.m_major ? Cr * KK : KK;
     d.w_ks = g.m_major ? KK : M * KK;
     d.w_bytes = M * Cr * KK * 4;
+    G2S_REQUIRE(groups >= 1 && groups <= 8 && (groups == 1 || (!in_scale && !out_scale && !f16_operands)),
+                "grouped launches take no input / output scales and fp32 operands");
+    d.groups = groups;
+    d.Cx = groups * Cr;
+    d.My = groups * M;
     bool holes = false;  // output positions no class writes (zero-filled)
     if (!g.adjoint) {
         G2S_REQUIRE(H + 2 * p_ >= k && W + 2 * p_ >= k, "input smaller than the kernel");
@@ -711,20 +728,20 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
         nmax = std::max(nmax, (long)B * d.cls[i].OH * d.cls[i].OW);
         kt_min = std::min(kt_min, ktiles_of(d.Cr, d.cls[i].T));
     }
-    G2S_REQUIRE(nmax < (1l << 30) && (long)B * d.Cr * H * W < (1l << 29) && (long)M * Cr * KK < (1l << 29),
+    G2S_REQUIRE(nmax < (1l << 30) && (long)B * d.Cx * H * W < (1l << 29) && (long)groups * M * Cr * KK < (1l << 29),
                 "problem too large for 32-bit byte offsets");
     hipStream_t st = as_stream(stream);
     const int cfgs[3][2] = {{128, 128}, {128, 64}, {64, 64}};
     int pick = 2;
     for (int i = 0; i < 3; i++) {
-        const long blocks = (long)cdiv(d.M, cfgs[i][0]) * cdiv(nmax, cfgs[i][1]) * d.ncls;
+        const long blocks = (long)groups * cdiv(d.M, cfgs[i][0]) * cdiv(nmax, cfgs[i][1]) * d.ncls;
         if (d.M > cfgs[i][0] / 2 && blocks >= 512) { pick = i; break; }
     }
     if (tuned_tile >= 0 && g_force_tile != -2) pick = tuned_tile;
     else tuned_splitk = -1;
     if (g_force_tile >= 0) pick = g_force_tile;
     const int BMv = cfgs[pick][0], BNv = cfgs[pick][1];
-    const int tiles = cdiv(d.M, BMv) * cdiv(nmax, BNv);
+    const int tiles = groups * cdiv(d.M, BMv) * cdiv(nmax, BNv);
     int splitk = 1;
     while ((long)tiles * d.ncls * splitk < 512 && kt_min / (splitk * 2) >= 8 && splitk < 64) splitk *= 2;
     if (tuned_splitk > 0) splitk = tuned_splitk;
@@ -739,7 +756,7 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
     }
     d.splitk = splitk;
     if ((splitk > 1 || holes) && !y_is_zero) {
-        if (hipMemsetAsync(y, 0, (size_t)B * d.M * d.OHf * d.OWf * sizeof(float), st) != hipSuccess)
+        if (hipMemsetAsync(y, 0, (size_t)B * d.My * d.OHf * d.OWf * sizeof(float), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
     }
     dim3 grid(tiles, splitk, d.ncls);
@@ -760,8 +777,8 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
     }
     int rc = check_launch("g2s_modconv");
     if (rc != G2S_OK || !deferred_epilogue) return rc;
-    return g2s_fused_bias_act(y, bias, nullptr, y, (int64_t)B * d.M * d.OHf * d.OWf,
-                              (int64_t)d.OHf * d.OWf, d.M, act ? 3 : 1, 0, act_alpha,
+    return g2s_fused_bias_act(y, bias, nullptr, y, (int64_t)B * d.My * d.OHf * d.OWf,
+                              (int64_t)d.OHf * d.OWf, d.My, act ? 3 : 1, 0, act_alpha,
                               act ? act_gain : 1.0f, G2S_F32, stream);
 }
 
@@ -820,14 +837,13 @@ extern "C" int g2s_conv_bias_act(const float *x, const float *w, const float *bi
                           mode, 0, stream);
 }
 
-extern "C" int g2s_conv2d(const float *x, const float *w, const float *bias, float *y, int B, int Cr,
-                          int M, int H, int W, int k, int stride, int pad, int adjoint, int w_m_major,
-                          int out_h, int out_w, int act, float alpha, float gain, int y_is_zero,
-                          g2s_stream_t stream) {
+static int conv2d_impl(const float *x, const float *w, const float *bias, float *y, int B, int Cr, int M, int H,
+                       int W, int k, int stride, int pad, int adjoint, int w_m_major, int out_h, int out_w,
+                       int act, float alpha, float gain, int y_is_zero, int groups, g2s_stream_t stream) {
     G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
     ConvGeom g{k, stride, pad, adjoint ? 1 : 0, w_m_major ? 1 : 0, adjoint ? out_h : 0, adjoint ? out_w : 0};
     int tile = -1, splitk = -1;
-    if (H == W)
+    if (H == W && groups == 1)
         for (const TunedConv2d *t = kTuned2d; t->B; ++t)
             if (t->B == B && t->Cr == Cr && t->M == M && t->H == H && t->k == k && t->stride == stride &&
                 t->pad == pad && t->adjoint == g.adjoint && t->m_major == g.m_major &&
@@ -837,5 +853,21 @@ extern "C" int g2s_conv2d(const float *x, const float *w, const float *bias, flo
                 break;
             }
     return conv_launch(x, w, nullptr, nullptr, bias, act, alpha, gain, y, B, Cr, M, H, W, g, tile, splitk, stream,
-                       y_is_zero != 0);
+                       y_is_zero != 0, false, groups);
+}
+
+extern "C" int g2s_conv2d(const float *x, const float *w, const float *bias, float *y, int B, int Cr,
+                          int M, int H, int W, int k, int stride, int pad, int adjoint, int w_m_major,
+                          int out_h, int out_w, int act, float alpha, float gain, int y_is_zero,
+                          g2s_stream_t stream) {
+    return conv2d_impl(x, w, bias, y, B, Cr, M, H, W, k, stride, pad, adjoint, w_m_major, out_h, out_w, act, alpha,
+                       gain, y_is_zero, 1, stream);
+}
+
+extern "C" int g2s_conv2d_grouped(const float *x, const float *w, const float *bias, float *y, int B, int Cr,
+                                  int M, int H, int W, int k, int stride, int pad, int adjoint, int w_m_major,
+                                  int out_h, int out_w, int act, float alpha, float gain, int y_is_zero,
+                                  int groups, g2s_stream_t stream) {
+    return conv2d_impl(x, w, bias, y, B, Cr, M, H, W, k, stride, pad, adjoint, w_m_major, out_h, out_w, act, alpha,
+                       gain, y_is_zero, groups, stream);
 }

@@ -76,6 +76,14 @@ class GAN2Shape(nn.Module):
         self.albedo_net = networks.AlbedoNet(self.image_size, self.debug).to(self.device)
         self.offset_encoder_net = networks.OffsetEncoder(self.image_size, debug=self.debug).to(self.device)
 
+        # depth + albedo and viewpoint + lighting are pairs of the same architecture on the same input
+        # (networks.py:53-167): on the GPU each pair runs as ONE pass with grouped convolutions —
+        # half the launches of these launch-latency-bound nets; per net the arithmetic is unchanged
+        self.paired_nets = bool(config.get('paired_nets', True)) and self.device.type == 'cuda'
+        if self.paired_nets:
+            networks.pair_parameters(self.depth_net, self.albedo_net)
+            networks.pair_parameters(self.viewpoint_net, self.lighting_net)
+
         # Misc (model.py:48-66)
         self.max_depth = 1.1
         self.min_depth = 0.9
@@ -232,7 +240,14 @@ class GAN2Shape(nn.Module):
             return job
 
         pre = kwargs.get('_nets')
-        if pre is None:  # the four nets read the same image and nothing else: independent chains
+        if pre is None and self.paired_nets:
+            depth_raw, albedo = networks.forward_pair(self.depth_net, self.albedo_net, images,
+                                                      train_a=not step1)
+            if step1:
+                depth_raw = depth_raw.detach()
+            with self._no_grad_if(step1):
+                view, lighting = networks.forward_pair(self.viewpoint_net, self.lighting_net, images)
+        elif pre is None:  # the four nets read the same image and nothing else: independent chains
             depth_raw, albedo, view, lighting = self._fork([
                 frozen_if_step1(self.depth_net, images), lambda: self.albedo_net(images),
                 frozen_if_step1(self.viewpoint_net, images), frozen_if_step1(self.lighting_net, images)])
@@ -375,9 +390,13 @@ class GAN2Shape(nn.Module):
         b = len(projected_samples)
         both = torch.cat([images[:1], projected_samples], 0) if len(images) == 1 else None
         if both is not None:
-            depth_raw, albedo1, view_all, light_all = self._fork([
-                lambda: self.depth_net(images), lambda: self.albedo_net(images),
-                lambda: self.viewpoint_net(both), lambda: self.lighting_net(both)])
+            if self.paired_nets:
+                depth_raw, albedo1 = networks.forward_pair(self.depth_net, self.albedo_net, images)
+                view_all, light_all = networks.forward_pair(self.viewpoint_net, self.lighting_net, both)
+            else:
+                depth_raw, albedo1, view_all, light_all = self._fork([
+                    lambda: self.depth_net(images), lambda: self.albedo_net(images),
+                    lambda: self.viewpoint_net(both), lambda: self.lighting_net(both)])
             # one split each (a single concatenation in backward) instead of two slices (a zero-fill
             # + copy each)
             view1, view = view_all.split([1, b])

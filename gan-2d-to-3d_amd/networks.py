@@ -18,22 +18,7 @@ def run_fused(mods, x):
     from .op import conv as gconv
     from .op.groupnorm import groupnorm_act, supported as gn_supported
     mods = list(mods)
-    # one cleared arena for the convolution outputs of this pass (see PassArena): sized by walking
-    # the spatial sizes through the module list
-    total, (H, W) = 0, (x.shape[2], x.shape[3])
-    for m in mods:
-        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
-            H, W = gconv.conv_out_hw(m, H, W)
-            n = x.shape[0] * m.out_channels * H * W
-            if n <= gconv.PassArena.LIMIT:
-                total += gconv.PassArena._pad(n)
-        elif isinstance(m, nn.Upsample):
-            H, W = int(H * m.scale_factor), int(W * m.scale_factor)
-        elif isinstance(m, (nn.AvgPool2d, nn.MaxPool2d)):
-            H, W = H // 2, W // 2
-        elif not isinstance(m, (nn.GroupNorm, nn.ReLU, nn.LeakyReLU, nn.Tanh, nn.Sigmoid)):
-            break  # unknown shape rule: later outputs simply keep their own allocation
-    arena = gconv.PassArena(x.device, total)
+    arena = _pass_arena(mods, x, 1)
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -56,6 +41,109 @@ def run_fused(mods, x):
             x = m(x)
             i += 1
     return x
+
+
+def _pass_arena(mods, x, width):
+    """One cleared arena for the convolution outputs of a pass (see PassArena), sized by walking the
+    spatial sizes through the module list; `width` = 2 for a paired pass (twice the channels)."""
+    from .op import conv as gconv
+    total, (H, W) = 0, (x.shape[2], x.shape[3])
+    for m in mods:
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            H, W = gconv.conv_out_hw(m, H, W)
+            n = x.shape[0] * m.out_channels * width * H * W
+            if n <= gconv.PassArena.LIMIT:
+                total += gconv.PassArena._pad(n)
+        elif isinstance(m, nn.Upsample):
+            H, W = int(H * m.scale_factor), int(W * m.scale_factor)
+        elif isinstance(m, (nn.AvgPool2d, nn.MaxPool2d)):
+            H, W = H // 2, W // 2
+        elif not isinstance(m, (nn.GroupNorm, nn.ReLU, nn.LeakyReLU, nn.Tanh, nn.Sigmoid)):
+            break  # unknown shape rule: later outputs simply keep their own allocation
+    return gconv.PassArena(x.device, total)
+
+
+def pair_parameters(net_a, net_b):
+    """Give every pair of equally shaped parameters of two structurally identical nets ONE storage
+    (a's tensor, then b's): the two nets can then run as a single network with twice the channels
+    and grouped convolutions (run_fused_pair), one launch per layer and direction instead of two.
+    Parameters stay the nets' own (same names, shapes, values; the optimisers update them in place);
+    call after the nets are on their device.  Returns the number of paired parameters."""
+    import torch
+    n = 0
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        if pa.shape != pb.shape or pa.dtype != pb.dtype or pa.device != pb.device:
+            continue
+        both = torch.cat([pa.data.reshape(-1), pb.data.reshape(-1)])
+        pa.data = both[:pa.numel()].view(pa.shape)
+        pb.data = both[pa.numel():].view(pb.shape)
+        n += 1
+    return n
+
+
+def run_fused_pair(mods_a, mods_b, x, train_a=True, train_b=True):
+    """Two structurally identical module lists on the SAME input as one pass: activations carry the
+    channels of net a followed by those of net b, convolutions run as grouped launches
+    (g2s_conv2d_grouped, groups = 2; the first layer is one plain convolution with both nets' filters),
+    GroupNorm sees twice the groups.  From the first layer whose parameters differ in shape (the nets'
+    heads: GAN2Shape/networks.py:53-76,144-167) the two halves continue on their own.  Per net the
+    arithmetic is that of run_fused.  train_x = False: that net's parameters get no gradient (the
+    reference's no_grad branches of step 1, model.py:99-131).  Returns (y_a, y_b)."""
+    import torch
+    from .op import conv as gconv
+    from .op.groupnorm import groupnorm_act, supported as gn_supported
+    mods_a, mods_b = list(mods_a), list(mods_b)
+
+    def pv(pa, pb):
+        return gconv.pair_view(pa if train_a else pa.detach(), pb if train_b else pb.detach())
+
+    groups = 1      # 1 until the first convolution has produced the side-by-side activations
+    arena = _pass_arena(mods_a, x, 2)
+    i = 0
+    while i < len(mods_a):
+        ma, mb = mods_a[i], mods_b[i]
+        nxt = mods_a[i + 1] if i + 1 < len(mods_a) else None
+        slope = nxt.negative_slope if isinstance(nxt, nn.LeakyReLU) else 0.0 if isinstance(nxt, nn.ReLU) else None
+        if isinstance(ma, (nn.Conv2d, nn.ConvTranspose2d)):
+            if not (gconv.adjacent(ma.weight, mb.weight) and ma.bias is None and mb.bias is None
+                    and gconv.supported(ma, x[:, :ma.in_channels])
+                    and not (groups == 1 and isinstance(ma, nn.ConvTranspose2d))):
+                break
+            x = gconv.ConvFunction.apply(x, pv(ma.weight, mb.weight), None, ma.stride[0], ma.padding[0],
+                                         isinstance(ma, nn.ConvTranspose2d), slope, arena, groups)
+            groups = 2
+            i += 2 if slope is not None else 1
+        elif isinstance(ma, nn.GroupNorm) and slope is not None and groups == 2 and gn_supported(x) \
+                and gconv.adjacent(ma.weight, mb.weight) and gconv.adjacent(ma.bias, mb.bias):
+            x = groupnorm_act(x, pv(ma.weight, mb.weight), pv(ma.bias, mb.bias), 2 * ma.num_groups, ma.eps, True, slope)
+            i += 2
+        elif isinstance(ma, (nn.ReLU, nn.LeakyReLU, nn.Upsample, nn.Tanh)) and groups == 2:
+            x = ma(x)
+            i += 1
+        else:
+            break
+    if groups == 1:
+        xa = xb = x
+    else:
+        c = x.shape[1] // 2
+        xa, xb = x[:, :c].contiguous(), x[:, c:].contiguous()
+    def tail(mods, xin, train):
+        if i >= len(mods):
+            return xin if train else xin.detach()
+        if train:
+            return run_fused(mods[i:], xin)
+        with torch.no_grad():      # a frozen net: no graph through its own head either
+            return run_fused(mods[i:], xin)
+    return tail(mods_a, xa, train_a), tail(mods_b, xb, train_b)
+
+
+def forward_pair(net_a, net_b, x, train_a=True, train_b=True):
+    """net_a(x), net_b(x) for two nets of the same class whose parameters were paired
+    (pair_parameters): one pass with twice the channels on the GPU, the plain two calls otherwise."""
+    if x.is_cuda and type(net_a).__mro__[1] is type(net_b).__mro__[1] and hasattr(net_a, "_finish"):
+        ya, yb = run_fused_pair(net_a.network, net_b.network, x, train_a, train_b)
+        return net_a._finish(ya, x), net_b._finish(yb, x)
+    return net_a(x), net_b(x)
 
 
 class Encoder(nn.Module):
@@ -83,9 +171,13 @@ class Encoder(nn.Module):
                    nn.Tanh()]
         self.network = nn.Sequential(*layers)
 
+    @staticmethod
+    def _finish(out, input):
+        return out.reshape(input.size(0), -1)
+
     def forward(self, input):
         out = run_fused(self.network, input) if input.is_cuda else self.network(input)
-        return out.reshape(input.size(0), -1)
+        return self._finish(out, input)
 
 
 class ViewpointNet(Encoder):
@@ -136,6 +228,10 @@ class EncoderDecoder(nn.Module):
         if activation is not None:
             network += [activation()]
         self.network = nn.Sequential(*network)
+
+    @staticmethod
+    def _finish(out, input):
+        return out
 
     def forward(self, input):
         return run_fused(self.network, input) if input.is_cuda else self.network(input)

@@ -68,52 +68,69 @@ def conv_out_hw(mod, H, W):
     return (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
 
 
-def _conv2d_raw(x, w, bias, Cr, M, k, stride, pad, adjoint, m_major, out_hw, act, slope, out=None):
+def _conv2d_raw(x, w, bias, Cr, M, k, stride, pad, adjoint, m_major, out_hw, act, slope, out=None, groups=1):
+    """Cr -> M channels PER GROUP; x has groups * Cr channels, y groups * M (g2s_conv2d_grouped)."""
     B, _, H, W = x.shape
     if adjoint:
         oh, ow = out_hw if out_hw else ((H - 1) * stride - 2 * pad + k, (W - 1) * stride - 2 * pad + k)
     else:
         oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     zeroed = out is not None
-    y = out if zeroed else torch.empty((B, M, oh, ow), dtype=torch.float32, device=x.device)
-    assert tuple(y.shape) == (B, M, oh, ow)
+    y = out if zeroed else torch.empty((B, groups * M, oh, ow), dtype=torch.float32, device=x.device)
+    assert tuple(y.shape) == (B, groups * M, oh, ow) and x.shape[1] == groups * Cr
     L = _lib.load()
     from gan2shape_amd.modconv import profiled
     sp = H * W if adjoint else oh * ow  # every (input pixel, tap) pair of the strided side once
-    with profiled(2.0 * B * Cr * M * k * k * sp, 4.0 * (x.numel() + w.numel() + y.numel())):
-        _lib.check(L.g2s_conv2d(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W, k,
-                                stride, pad, int(adjoint), int(m_major), oh if adjoint else 0,
-                                ow if adjoint else 0, 1 if act else 0, float(slope), 1.0, int(zeroed),
-                                _lib.stream()))
+    with profiled(2.0 * B * groups * Cr * M * k * k * sp, 4.0 * (x.numel() + w.numel() + y.numel())):
+        if groups == 1:
+            _lib.check(L.g2s_conv2d(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W, k,
+                                    stride, pad, int(adjoint), int(m_major), oh if adjoint else 0,
+                                    ow if adjoint else 0, 1 if act else 0, float(slope), 1.0, int(zeroed),
+                                    _lib.stream()))
+        else:
+            _lib.check(L.g2s_conv2d_grouped(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W,
+                                            k, stride, pad, int(adjoint), int(m_major), oh if adjoint else 0,
+                                            ow if adjoint else 0, 1 if act else 0, float(slope), 1.0,
+                                            int(zeroed), groups, _lib.stream()))
     return y
 
 
-def _wgrad(A, G, k, stride, pad, out=None):
+def _wgrad(A, G, k, stride, pad, out=None, groups=1):
+    """dw [groups * Ca, Cg, k, k] from A [B, groups * Ca, ...] and G [B, groups * Cg, ...]."""
     B, Ca, PH, PW = A.shape
     _, Cg, GH, GW = G.shape
+    Ca, Cg = Ca // groups, Cg // groups
     zeroed = out is not None
-    dw = out if zeroed else torch.empty((Ca, Cg, k, k), dtype=torch.float32, device=A.device)
+    dw = out if zeroed else torch.empty((groups * Ca, Cg, k, k), dtype=torch.float32, device=A.device)
     L = _lib.load()
-    _lib.check(L.g2s_conv2d_wgrad(_lib.ptr(A), _lib.ptr(G), _lib.ptr(dw), B, Ca, Cg, PH, PW, GH, GW, k,
-                                  stride, pad, int(zeroed), _lib.stream()))
+    if groups == 1:
+        _lib.check(L.g2s_conv2d_wgrad(_lib.ptr(A), _lib.ptr(G), _lib.ptr(dw), B, Ca, Cg, PH, PW, GH, GW, k,
+                                      stride, pad, int(zeroed), _lib.stream()))
+    else:
+        _lib.check(L.g2s_conv2d_wgrad_grouped(_lib.ptr(A), _lib.ptr(G), _lib.ptr(dw), B, Ca, Cg, PH, PW, GH, GW,
+                                              k, stride, pad, int(zeroed), groups, _lib.stream()))
     return dw
 
 
 class ConvFunction(Function):
     """transposed = False: F.conv2d(x, w [Cout,Cin,k,k], bias, stride, pad); True:
     F.conv_transpose2d(x, w [Cin,Cout,k,k], bias, stride, pad); then leaky-ReLU(slope) if
-    slope is not None (0 = ReLU)."""
+    slope is not None (0 = ReLU).
+    groups = 2: two such convolutions side by side (channels of x, rows of w and channels of y hold
+    the two nets one after the other) in one launch per direction."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, transposed, slope, arena=None):
+    def forward(ctx, x, w, bias, stride, pad, transposed, slope, arena=None, groups=1):
         _lib.require_cuda(x, w, bias)
         if x.dtype != torch.float32 or w.dtype != torch.float32:
             raise RuntimeError("conv: float32 only")
         x, w = x.contiguous(), w.contiguous()
         k = w.shape[2]
-        cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
-        if x.shape[1] != cin:
-            raise RuntimeError(f"conv: input has {x.shape[1]} channels, weight expects {cin}")
+        cin, cout = (w.shape[0] // groups, w.shape[1]) if transposed else (w.shape[1], w.shape[0] // groups)
+        if x.shape[1] != groups * cin:
+            raise RuntimeError(f"conv: input has {x.shape[1]} channels, weight expects {groups * cin}")
+        if groups != 1 and bias is not None:
+            raise RuntimeError("grouped conv: no bias")
         b = None if bias is None else bias.contiguous()
         out = None
         if arena is not None:
@@ -122,40 +139,41 @@ class ConvFunction(Function):
                 oh, ow = (H - 1) * stride - 2 * pad + k, (W - 1) * stride - 2 * pad + k
             else:
                 oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-            out = arena.take_fwd((x.shape[0], cout, oh, ow))
+            out = arena.take_fwd((x.shape[0], groups * cout, oh, ow))
             if ctx.needs_input_grad[0]:
                 arena.reserve_bwd(x.numel())
             if ctx.needs_input_grad[1]:
                 arena.reserve_bwd(w.numel())
         y = _conv2d_raw(x, w, b, cin, cout, k, stride, pad, transposed, not transposed, None,
-                        slope is not None, slope or 0.0, out=out)
+                        slope is not None, slope or 0.0, out=out, groups=groups)
         ctx.save_for_backward(x, w, y if slope is not None else None)
-        ctx.cfg = (stride, pad, transposed, slope, bias is not None)
+        ctx.cfg = (stride, pad, transposed, slope, bias is not None, groups)
         ctx.arena = arena
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
-        stride, pad, transposed, slope, has_bias = ctx.cfg
+        stride, pad, transposed, slope, has_bias, groups = ctx.cfg
         k = w.shape[2]
         gy = gy.contiguous()
         if slope is not None:  # gradient through the fused activation: slope taken from sign(y)
             from gan2shape_amd.plugins import fused
             gy = fused.fused_bias_act(gy, gy.new_empty(0), y, 3, 1, float(slope), 1.0)
-        cin, cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+        cin, cout = (w.shape[0] // groups, w.shape[1]) if transposed else (w.shape[1], w.shape[0] // groups)
         gx = gw = gb = None
         arena = ctx.arena
         if ctx.needs_input_grad[0]:
             out = None if arena is None else arena.take_bwd(tuple(x.shape))
             gx = _conv2d_raw(gy, w, None, cout, cin, k, stride, pad, not transposed, transposed,
-                             (x.shape[2], x.shape[3]), False, 0.0, out=out)
+                             (x.shape[2], x.shape[3]), False, 0.0, out=out, groups=groups)
         if ctx.needs_input_grad[1]:
             out = None if arena is None else arena.take_bwd(tuple(w.shape))
-            gw = _wgrad(x, gy, k, stride, pad, out) if transposed else _wgrad(gy, x, k, stride, pad, out)
+            gw = (_wgrad(x, gy, k, stride, pad, out, groups) if transposed
+                  else _wgrad(gy, x, k, stride, pad, out, groups))
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3))
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 def supported(mod, x):
@@ -175,3 +193,32 @@ def conv_module(mod, x, slope=None, arena=None):
     transposed = isinstance(mod, torch.nn.ConvTranspose2d)
     return ConvFunction.apply(x, mod.weight, mod.bias, mod.stride[0], mod.padding[0], transposed, slope,
                               arena)
+
+
+# ------------------------------------------------------------------------------------- paired nets
+class PairView(Function):
+    """Two parameters of equal shape that live back to back in ONE storage (networks.pair_parameters)
+    seen as a single tensor [2 * n0, ...]: what a grouped launch reads.  Gradients split back."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.n = a.numel()
+        ctx.shape = a.shape
+        return torch.as_strided(a.detach(), (2 * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        n0 = ctx.shape[0]
+        return g[:n0], g[n0:]
+
+
+def adjacent(a, b):
+    """True if parameter b starts where parameter a ends (same storage, same shape, contiguous)."""
+    return (a.shape == b.shape and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel())
+
+
+def pair_view(a, b):
+    return PairView.apply(a, b)

@@ -191,6 +191,19 @@ int g2s_conv2d(const float *x, const float *w, const float *bias, float *y, int 
                int act, float alpha, float gain, int y_is_zero, g2s_stream_t stream);
 int g2s_conv2d_wgrad(const float *A, const float *G, float *dw, int B, int Ca, int Cg, int PH, int PW,
                      int GH, int GW, int k, int stride, int pad, int dw_is_zero, g2s_stream_t stream);
+/* `groups` independent convolutions in one launch — two structurally identical trained nets (depth +
+ * albedo, viewpoint + lighting: GAN2Shape/networks.py:53-167 differ only in their last layer) run
+ * with their channels side by side: x [B, groups*Cr, H, W], y [B, groups*M, ...], w and bias hold the
+ * groups back to back ([groups][M][Cr][k][k], or [groups][Cr][M][k][k] when w_m_major = 0); for the
+ * weight gradient A [B, groups*Ca, ...], G [B, groups*Cg, ...], dw [groups][Ca][Cg][k][k].  Per
+ * group the arithmetic is that of g2s_conv2d / g2s_conv2d_wgrad. */
+int g2s_conv2d_grouped(const float *x, const float *w, const float *bias, float *y, int B, int Cr, int M,
+                       int H, int W, int k, int stride, int pad, int adjoint, int w_m_major, int out_h,
+                       int out_w, int act, float alpha, float gain, int y_is_zero, int groups,
+                       g2s_stream_t stream);
+int g2s_conv2d_wgrad_grouped(const float *A, const float *G, float *dw, int B, int Ca, int Cg, int PH,
+                             int PW, int GH, int GW, int k, int stride, int pad, int dw_is_zero, int groups,
+                             g2s_stream_t stream);
 
 /* fp16-OPERAND form of g2s_modconv / g2s_conv_bias_act (BASELINE config 5, "fp16 MFMA path"): same
  * arguments and geometry; x, w, y stay fp32 in memory, both GEMM operands are rounded to fp16 on

@@ -523,3 +523,40 @@ def test_renderer_texture_helpers_on_gpu(g2s):
     assert tuple(gs.shape) == (1, 3, 3, S, S) and bool(torch.isfinite(gs).all())
     crop = R.render_yaw(im, depth, maxr=10, nsample=3, crop_mesh=(2, 2, 3, 3))
     assert tuple(crop.shape) == (1, 3, 3, S, S)
+
+
+# ----------------------------------------------------------------------------- paired nets (grouped launches)
+@pytest.mark.parametrize("names,B", [(("DepthNet", "AlbedoNet"), 1), (("ViewpointNet", "LightingNet"), 1),
+                                     (("ViewpointNet", "LightingNet"), 5)])
+def test_paired_nets_equal_the_two_nets(g2s, names, B):
+    """forward_pair (one pass with twice the channels: g2s_conv2d_grouped / g2s_conv2d_wgrad_grouped,
+    GroupNorm over twice the groups) against the same two nets run one after the other: outputs
+    and every parameter gradient — also with one net frozen (step 1: only the albedo net trains)."""
+    import copy
+    from gan2shape_amd import networks
+    torch.manual_seed(0)
+    a, b = getattr(networks, names[0])(128).cuda(), getattr(networks, names[1])(128).cuda()
+    a2, b2 = copy.deepcopy(a), copy.deepcopy(b)
+    assert networks.pair_parameters(a, b) >= len(list(a.parameters())) - 1
+    for p, q in zip(list(a.parameters()) + list(b.parameters()), list(a2.parameters()) + list(b2.parameters())):
+        assert torch.equal(p, q)                                    # pairing moves storage, not values
+    x = torch.randn(B, 3, 128, 128, device="cuda")
+    for train_a in (True, False):
+        ya, yb = networks.forward_pair(a, b, x, train_a=train_a)
+        ra, rb = a2(x), b2(x)
+        torch.testing.assert_close(ya, ra, rtol=1e-4, atol=1e-5 * float(ra.abs().max()))
+        torch.testing.assert_close(yb, rb, rtol=1e-4, atol=1e-5 * float(rb.abs().max()))
+        ga, gb = torch.randn_like(ra), torch.randn_like(rb)
+        for net in (a, b, a2, b2):
+            for p in net.parameters():
+                p.grad = None
+        ((ya * ga).sum() + (yb * gb).sum()).backward()
+        ((ra * ga).sum() * (1.0 if train_a else 0.0) + (rb * gb).sum()).backward()
+        frozen = set() if train_a else {id(p) for p in a.parameters()}
+        for (n, p), q in zip(list(a.named_parameters()) + list(b.named_parameters()),
+                             list(a2.parameters()) + list(b2.parameters())):
+            if id(p) in frozen:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, n     # no gradient reaches a frozen net
+                continue
+            err = float((p.grad - q.grad).norm())
+            assert err <= 2e-3 * float(q.grad.norm()) + 1e-7, (n, err, float(q.grad.norm()))
