@@ -27,6 +27,7 @@ SOURCES = {
     "winograd.hip": ["-fno-slp-vectorize"],
     "rowops.hip": [],
     "lpips.hip": [],
+    "losses.hip": [],
     "geometry.hip": ["-ffp-contract=off"],
     "groupnorm.hip": [],
     "conv_wgrad.hip": [],

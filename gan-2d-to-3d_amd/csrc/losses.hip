@@ -1,0 +1,94 @@
+// losses.hip — masked / weighted L1 between two feature tensors in one pass per direction:
+//     num = sum_{b,c,p} |x[b,c,p] - y[b,c,p]| * w[b,p]        (w == NULL: weight 1)
+// the numerator of PhotometricLoss and of every level of DiscriminatorLoss
+// (GAN2Shape/losses.py:6-51: loss = (|a - b| * mask.expand_as).sum() / mask.expand_as.sum(), which the
+// reference runs as sub, abs, expand, mul, two full-size sums and a division per level).  The
+// denominator C * sum(w) needs only the small weight map and stays on the host side (torch).
+// Backward: gx = sign(x - y) * w * coef[0]  (coef = incoming gradient / denominator, a device scalar).
+#include <algorithm>
+#include "g2s_common.h"
+
+namespace g2s {
+
+constexpr int WL1_THREADS = 256;
+
+__device__ __forceinline__ float wl1_block_sum(float v, float *sm) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    return (threadIdx.x == 0) ? (sm[0] + sm[1]) + (sm[2] + sm[3]) : 0.0f;
+}
+
+// x, y [B, C, HW]; w [B, HW] or NULL.  grid (chunks of 4 * 256 * UNROLL floats per (b, c) plane..)
+__global__ __launch_bounds__(WL1_THREADS) void wl1_fwd(const float *__restrict__ x, const float *__restrict__ y,
+                                                       const float *__restrict__ w, float *__restrict__ num,
+                                                       int C, int HW4, long total4) {
+    __shared__ float sm[4];
+    float acc = 0.0f;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *y4 = reinterpret_cast<const float4 *>(y);
+    const float4 *w4 = reinterpret_cast<const float4 *>(w);
+    for (long i = (long)blockIdx.x * WL1_THREADS + threadIdx.x; i < total4; i += (long)gridDim.x * WL1_THREADS) {
+        const float4 a = x4[i], b = y4[i];
+        float4 m = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        if (w) {
+            const long plane = i / HW4;              // b * C + c
+            m = w4[(plane / C) * HW4 + (i - plane * HW4)];
+        }
+        acc += (fabsf(a.x - b.x) * m.x + fabsf(a.y - b.y) * m.y) + (fabsf(a.z - b.z) * m.z + fabsf(a.w - b.w) * m.w);
+    }
+    const float s = wl1_block_sum(acc, sm);
+    if (threadIdx.x == 0) unsafeAtomicAdd(num, s);
+}
+
+__global__ __launch_bounds__(WL1_THREADS) void wl1_bwd(const float *__restrict__ x, const float *__restrict__ y,
+                                                       const float *__restrict__ w, const float *__restrict__ coef,
+                                                       float *__restrict__ gx, int C, int HW4, long total4) {
+    const float k = coef[0];
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *y4 = reinterpret_cast<const float4 *>(y);
+    const float4 *w4 = reinterpret_cast<const float4 *>(w);
+    float4 *g4 = reinterpret_cast<float4 *>(gx);
+    for (long i = (long)blockIdx.x * WL1_THREADS + threadIdx.x; i < total4; i += (long)gridDim.x * WL1_THREADS) {
+        const float4 a = x4[i], b = y4[i];
+        float4 m = make_float4(k, k, k, k);
+        if (w) {
+            const long plane = i / HW4;
+            const float4 ww = w4[(plane / C) * HW4 + (i - plane * HW4)];
+            m = make_float4(ww.x * k, ww.y * k, ww.z * k, ww.w * k);
+        }
+        auto sgn = [](float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); };   // torch: sign(0) = 0
+        g4[i] = make_float4(sgn(a.x - b.x) * m.x, sgn(a.y - b.y) * m.y, sgn(a.z - b.z) * m.z, sgn(a.w - b.w) * m.w);
+    }
+}
+
+}  // namespace g2s
+
+using namespace g2s;
+
+static int wl1_check(const void *x, const void *y, int B, int C, int HW) {
+    G2S_REQUIRE(x && y, "NULL pointer argument");
+    G2S_REQUIRE(B > 0 && C > 0 && HW > 0 && HW % 4 == 0, "sizes must be positive, HW a multiple of 4");
+    return G2S_OK;
+}
+
+extern "C" int g2s_weighted_l1_fwd(const float *x, const float *y, const float *w, float *num, int B, int C,
+                                   int HW, g2s_stream_t stream) {
+    int rc = wl1_check(x, y, B, C, HW);
+    if (rc) return rc;
+    G2S_REQUIRE(num, "num must not be NULL (a ZEROED device float: the sum is accumulated into it)");
+    const long total4 = (long)B * C * HW / 4;
+    const int blocks = (int)std::min<long>(cdiv(total4, WL1_THREADS * 4), 2048);
+    wl1_fwd<<<blocks, WL1_THREADS, 0, as_stream(stream)>>>(x, y, w, num, C, HW / 4, total4);
+    return check_launch("g2s_weighted_l1_fwd");
+}
+
+extern "C" int g2s_weighted_l1_bwd(const float *x, const float *y, const float *w, const float *coef, float *gx,
+                                   int B, int C, int HW, g2s_stream_t stream) {
+    int rc = wl1_check(x, y, B, C, HW);
+    if (rc) return rc;
+    G2S_REQUIRE(coef && gx, "NULL pointer argument");
+    const long total4 = (long)B * C * HW / 4;
+    const int blocks = (int)std::min<long>(cdiv(total4, WL1_THREADS * 4), 4096);
+    wl1_bwd<<<blocks, WL1_THREADS, 0, as_stream(stream)>>>(x, y, w, coef, gx, C, HW / 4, total4);
+    return check_launch("g2s_weighted_l1_bwd");
+}

@@ -13,6 +13,50 @@ def _weighted_mean(err, weight):
     return (err * weight).sum() / weight.sum()
 
 
+class _WeightedL1(torch.autograd.Function):
+    """sum(|x - y| * w.expand_as(x)) / sum(w.expand_as(x)) for x, y (B, C, H, W) and a mask w
+    (B, 1, H, W) — one kernel per direction (g2s_weighted_l1_fwd / _bwd) instead of sub, abs, expand,
+    mul and two full-size reductions.  Gradient w.r.t. x only (y is the detached real branch / the
+    target image, w a detached mask)."""
+
+    @staticmethod
+    def forward(ctx, x, y, w):
+        from . import lib as _lib
+        x, y = x.contiguous(), y.contiguous()
+        B, C, H, W = x.shape
+        L = _lib.load()
+        num = torch.zeros((), dtype=torch.float32, device=x.device)
+        wc = None if w is None else w.contiguous()
+        _lib.check(L.g2s_weighted_l1_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(wc), _lib.ptr(num), B, C, H * W,
+                                         _lib.stream()))
+        den = (wc.sum() * C) if wc is not None else float(x.numel())
+        ctx.save_for_backward(x, y, wc, den if torch.is_tensor(den) else None)
+        ctx.den = None if torch.is_tensor(den) else den
+        return num / den
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import lib as _lib
+        x, y, wc, den = ctx.saved_tensors
+        coef = (g / (den if den is not None else ctx.den)).reshape(1).float().contiguous()
+        gx = torch.empty_like(x)
+        B, C, H, W = x.shape
+        L = _lib.load()
+        _lib.check(L.g2s_weighted_l1_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(wc), _lib.ptr(coef), _lib.ptr(gx), B, C,
+                                         H * W, _lib.stream()))
+        return gx, None, None
+
+
+def _masked_l1(a, b, weight):
+    """(|a - b| * w).sum() / w.sum() with w (B,1,H,W) or (B,C,H,W)-expandable; fused on the GPU."""
+    if (a.is_cuda and a.dtype == torch.float32 and a.dim() == 4 and a.shape == b.shape and not b.requires_grad
+            and (a.shape[2] * a.shape[3]) % 4 == 0
+            and (weight is None or (weight.dim() == 4 and weight.shape[1] == 1 and weight.shape[0] == a.shape[0]
+                                    and weight.shape[2:] == a.shape[2:] and not weight.requires_grad))):
+        return _WeightedL1.apply(a, b, weight)
+    return _weighted_mean((a - b).abs(), weight)
+
+
 class DiscriminatorLoss():
     """Sum over the first `ftr_num` discriminator feature maps of the L1 distance between the
     features of `fake_img` and `real_img`; a mask is box-averaged down to each feature resolution
@@ -32,12 +76,20 @@ class DiscriminatorLoss():
         fake = self._features(D, fake_img)
         count = len(fake) if self.ftr_num is None else self.ftr_num
         total = 0
+        pooled = {}     # mask averaged down to a feature resolution, each level from the previous one
         for f_fake, f_real in zip(fake[:count], real[:count]):
             weight = None
             if mask is not None:
                 step = (mask.shape[2] // f_fake.shape[2], mask.shape[3] // f_fake.shape[3])
-                weight = F.avg_pool2d(mask, kernel_size=step, stride=step)
-            total = total + _weighted_mean((f_fake - f_real).abs(), weight)
+                weight = pooled.get(step)
+                if weight is None:
+                    # box average over step x step (losses.py:27-31); a power-of-two step is reached by
+                    # 2x2 averages of the previous level (same value, sums re-associated)
+                    prev = pooled.get((step[0] // 2, step[1] // 2)) if step[0] % 2 == 0 and step[1] % 2 == 0 else None
+                    weight = F.avg_pool2d(prev, 2, 2) if prev is not None else \
+                        F.avg_pool2d(mask, kernel_size=step, stride=step)
+                    pooled[step] = weight
+            total = total + _masked_l1(f_fake, f_real, weight)
         return total
 
 
@@ -47,10 +99,11 @@ class PhotometricLoss():
     EPS = 1e-7
 
     def __call__(self, image1, image2, mask=None, conf_sigma=None):
+        if conf_sigma is None:
+            return _masked_l1(image1, image2, mask)
         err = (image1 - image2).abs()
-        if conf_sigma is not None:
-            sigma = conf_sigma + self.EPS
-            err = err * 2 ** 0.5 / sigma + sigma.log()
+        sigma = conf_sigma + self.EPS
+        err = err * 2 ** 0.5 / sigma + sigma.log()
         return _weighted_mean(err, mask)
 
 

@@ -274,6 +274,19 @@ int g2s_lpips_layer_bwd(const float *f0, const float *f1, const float *w, const 
                         float *g0, int N, int C, int HW, g2s_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Masked L1 (csrc/losses.hip): the numerator of PhotometricLoss and of every DiscriminatorLoss level
+ * (GAN2Shape/losses.py:6-51: (|a - b| * mask.expand_as(loss)).sum() / mask.expand_as(loss).sum()).
+ * x, y [B, C, HW] f32; w [B, HW] (the mask at this resolution) or NULL (weight 1); HW % 4 == 0.
+ * _fwd: *num += sum |x - y| * w   (num: a ZEROED device float).  The denominator C * sum(w) only
+ *       needs the small mask and is left to the caller.
+ * _bwd: gx = sign(x - y) * w * coef[0]   (coef: device float = incoming gradient / denominator).
+ * ---------------------------------------------------------------------------------------- */
+int g2s_weighted_l1_fwd(const float *x, const float *y, const float *w, float *num, int B, int C, int HW,
+                        g2s_stream_t stream);
+int g2s_weighted_l1_bwd(const float *x, const float *y, const float *w, const float *coef, float *gx, int B,
+                        int C, int HW, g2s_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused renderer geometry / loss glue (csrc/geometry.hip).  All f32, device pointers; K is a HOST
  * pointer to 9 floats.  rays [H*W, 3] = K^-1 (u, v, 1)^T per pixel (renderer.py:74-80); R [B,3,3],
  * t [B,3]; rot_center_depth = z of the rotation centre (renderer.py:64-69).
