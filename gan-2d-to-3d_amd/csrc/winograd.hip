@@ -275,8 +275,9 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
                 } else if (q < 8) {
                     const int i = q - 4;
                     if constexpr (FAST) {
-                        const int left = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rd[i * 4 + 2]), 0x138, 0xf, 0xf, false);
-                        const int right = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rd[i * 4 + 1]), 0x130, 0xf, 0xf, false);
+                        // bound_ctrl: lanes without a source read 0 (no `old` operand to initialise)
+                        const int left = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, rd[i * 4 + 2]), 0x138, 0xf, 0xf, true);
+                        const int right = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, rd[i * 4 + 1]), 0x130, 0xf, 0xf, true);
                         rd[i * 4 + 0] = first_col ? 0.0f : __builtin_bit_cast(float, left);
                         rd[i * 4 + 3] = last_col ? 0.0f : __builtin_bit_cast(float, right);
                     }
