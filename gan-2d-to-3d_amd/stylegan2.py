@@ -407,16 +407,14 @@ class Generator(nn.Module):
         return _StyleRow(lat, pre)
 
     def make_noise(self):
+        """One [1,1,r,r] map per styled conv: 4, then two per octave up to `size` (model.py:468-477)."""
+        sides = [4] + [2 ** (3 + j // 2) for j in range(self.num_layers - 1)]
         device = self.input.input.device
-        noises = [torch.randn(1, 1, 2 ** 2, 2 ** 2, device=device)]
-        for i in range(3, self.log_size + 1):
-            for _ in range(2):
-                noises.append(torch.randn(1, 1, 2 ** i, 2 ** i, device=device))
-        return noises
+        return [torch.randn(1, 1, r, r, device=device) for r in sides]
 
     def mean_latent(self, n_latent):
-        latent_in = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
-        return self.style_forward(latent_in).mean(0, keepdim=True)
+        z = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
+        return self.style_forward(z).mean(0, keepdim=True)
 
     def get_latent(self, input):
         return self.style_forward(input)
@@ -445,6 +443,23 @@ class Generator(nn.Module):
             raise NotImplementedError("batchify > 0 is broken in the reference (model.py:524-531)")
         return self.invert_sub(latent_projection, truncation, mean_latent)
 
+    def _per_layer_latents(self, styles, inject_index):
+        """[B, n_latent, style_dim] from what the caller passed (model.py:568-600): one w (broadcast
+        to every layer, or already per layer), two ws (style mixing at `inject_index`), or one w per
+        layer.  GAN2Shape only ever passes one (model.py:189-190, 207-210)."""
+        n = self.n_latent
+        if len(styles) == 1:
+            w = styles[0]
+            return w if w.dim() == 3 else w[:, None].expand(-1, n, -1).contiguous()
+        if len(styles) == 2:
+            cut = random.randint(1, n - 1) if inject_index is None else inject_index
+            rows = [styles[0]] * cut + [styles[1]] * (n - cut)
+        elif len(styles) == n:
+            rows = list(styles)
+        else:
+            raise AssertionError(f'Expected {n} latents, got {len(styles)}')
+        return self.strided_style(torch.stack(rows, dim=1))
+
     def forward(self, styles, return_latents=False, inject_index=None, truncation=1,
                 truncation_latent=None, input_is_w=False, noise=None, randomize_noise=False,
                 return_features=False):
@@ -457,22 +472,7 @@ class Generator(nn.Module):
                 noise = [getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)]
         if truncation < 1:
             styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
-        if len(styles) == 1:
-            inject_index = self.n_latent
-            if styles[0].dim() < 3:
-                latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1)
-            else:
-                latent = styles[0]
-        elif len(styles) == 2:
-            if inject_index is None:
-                inject_index = random.randint(1, self.n_latent - 1)
-            latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1)
-            latent2 = styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)
-            latent = self.strided_style(torch.cat([latent, latent2], 1))
-        else:
-            assert len(styles) == self.n_latent, \
-                f'Expected {self.n_latent} latents, got {len(styles)}'
-            latent = self.strided_style(torch.stack(styles, dim=1))
+        latent = self._per_layer_latents(styles, inject_index)
 
         out = self.input(latent)
         # one unbind instead of 2 * n_latent selects: the backward is a single stack, not a
@@ -575,6 +575,16 @@ class Discriminator(nn.Module):
             EqualLinear(channels[4] * 4 * 4, channels[4], activation='fused_lrelu'),
             EqualLinear(channels[4], 1))
 
+    def _group_stddev(self, out):
+        """Minibatch-stddev feature (model.py:756-765): samples b, b+G', b+2G', ... form a group; the
+        per-element standard deviation over a group, averaged over (C / feat, H, W), is appended as
+        `feat` constant maps to every member."""
+        B, C, H, W = out.shape
+        G, F_ = min(B, self.stddev_group), self.stddev_feat
+        members = out.reshape(G, B // G, F_, C // F_, H * W)
+        spread = (members.var(0, unbiased=False) + 1e-8).sqrt().mean((2, 3))       # [B/G, feat]
+        return spread.repeat(G, 1)[:, :, None, None].expand(B, F_, H, W)
+
     def forward(self, input, ftr_num=100):
         out = input
         features = []
@@ -584,14 +594,8 @@ class Discriminator(nn.Module):
                 features.append(out)
             if len(features) >= ftr_num:
                 return 0, features
-        batch, channel, height, width = out.shape
-        group = min(batch, self.stddev_group)
-        stddev = out.view(group, -1, self.stddev_feat, channel // self.stddev_feat, height, width)
-        stddev = torch.sqrt(stddev.var(0, unbiased=False) + 1e-8)
-        stddev = stddev.mean((2, 3, 4), keepdim=True).squeeze(2)
-        stddev = stddev.repeat(group, 1, height, width)
-        out = torch.cat([out, stddev], 1)
+        out = torch.cat([out, self._group_stddev(out)], 1)
         out = self.final_conv(out)
         features.append(out)
-        out = self.final_linear(out.view(batch, -1))
+        out = self.final_linear(out.flatten(1))
         return out, features

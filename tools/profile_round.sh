@@ -24,6 +24,7 @@ bash $R/tools/profile_kinds.sh "1 2 3"
 cp $R/gpurun_out/kinds/step*.txt $O/
 echo "[6] micro-benchmarks"
 python3 $R/tools/bench_raster.py > $O/raster_microbench.txt 2>&1
-python3 $R/tools/conv_census.py > $O/conv_census.txt 2>&1
+python3 $R/tools/conv_census.py > $O/conv_census.txt 2>&1 || true
+python3 $R/tools/bench_wino.py 1 -256 > $O/wino_microbench.txt 2>&1 || true
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 echo done
