@@ -53,6 +53,7 @@ struct ConvDesc {
     // x has Cx = groups * Cr channels per sample, y has My = groups * M, w / bias hold the groups
     // back to back.  groups = 1: Cx = Cr, My = M.
     int groups, Cx, My;
+    int cls_splitk[4];   // split-K slices of each class (<= splitk = grid.y): lighter classes get fewer
     const float *bias;   // [M] added after out_scale, or NULL
     int act;             // 0: none, 1: leaky-ReLU(alpha) * gain applied after the bias
     float act_alpha, act_gain;
@@ -79,7 +80,8 @@ template <int BM, int BN, int T, bool PARTIAL, bool SCALE>
 __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass &c,
                                              float (&As)[2][KTile<T>::KMAX][BM + 1],
                                              float (&Bs)[2][KTile<T>::KMAX + 1][BN],
-                                             const int (&stab)[25], const int tile_id, const int grp) {
+                                             const int (&stab)[25], const int tile_id, const int grp,
+                                             const int kt_begin, const int kt_end, const bool atomic) {
     constexpr int BKT = KTile<T>::BKT, CPT = KTile<T>::CPT, BK_MAX = KTile<T>::KMAX;
     constexpr int WMT = BM / 64, WNT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
     constexpr bool WIDE = (T == 9);              // 9 contiguous taps per (m, channel): 3 x dwordx3
@@ -91,10 +93,6 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
     const int tiles_m = (d.M + BM - 1) / BM;
     const int m0 = (tile_id % tiles_m) * BM;
     const int n0 = (tile_id / tiles_m) * BN;
-    const int ktiles = (d.Cr + CPT - 1) / CPT;
-    const int per = (ktiles + d.splitk - 1) / d.splitk;
-    const int kt_begin = blockIdx.y * per;
-    const int kt_end = min(ktiles, kt_begin + per);
     const int HW = d.H * d.W;
     constexpr int OOB = 0x7fffffff;  // voffset beyond num_records: the buffer load returns 0
 
@@ -307,7 +305,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
                 if (gbias) v += gbias[m];
                 if (d.act) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
                 float *dst = yb + (size_t)m * d.OHf * d.OWf;
-                if (d.splitk > 1) unsafeAtomicAdd(dst, v);
+                if (atomic) unsafeAtomicAdd(dst, v);
                 else *dst = v;
             }
     }
@@ -318,72 +316,63 @@ static __host__ __device__ inline int ktiles_of(int Cr, int T) {
     return (Cr + cpt - 1) / cpt;
 }
 
+// One (class, tile, K range) segment: compile-time tap count; no partial-tile checks when the
+// channels fill the K tiles.
+template <int BM, int BN, int KMAX>
+__device__ __forceinline__ void modconv_segment(const ConvDesc &d, const ConvClass &c,
+                                                float (&As)[2][KMAX][BM + 1], float (&Bs)[2][KMAX + 1][BN],
+                                                const int (&stab)[25], const int tile_id, const int grp,
+                                                const int kb, const int ke, const bool atomic) {
+    const bool scale = d.in_scale != nullptr;
+#define G2S_BODY(T, PART, SC) modconv_body<BM, BN, T, PART, SC>(d, c, As, Bs, stab, tile_id, grp, kb, ke, atomic)
+#define G2S_TAPS(T, CPT)                                   \
+    if (d.Cr % CPT) {                                      \
+        if (scale) G2S_BODY(T, true, true);                \
+        else G2S_BODY(T, true, false);                     \
+    } else {                                               \
+        if (scale) G2S_BODY(T, false, true);               \
+        else G2S_BODY(T, false, false);                    \
+    }
+    if constexpr (KMAX == 26) {  // 5x5 (never modulated)
+        G2S_BODY(25, true, false);
+    } else {
+        switch (c.T) {
+        case 9: G2S_TAPS(9, 2) break;
+        case 16: G2S_BODY(16, true, false); break;  // 4x4 (never modulated)
+        case 4: G2S_TAPS(4, 4) break;
+        case 2: G2S_TAPS(2, 8) break;
+        default: G2S_TAPS(1, 16) break;
+        }
+    }
+#undef G2S_TAPS
+#undef G2S_BODY
+}
+
 template <int BM, int BN, int KMAX>
 __global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
     __shared__ float As[2][KMAX][BM + 1];
     __shared__ float Bs[2][KMAX + 1][BN];
     __shared__ int stab[25];
-    const ConvClass &c = d.cls[blockIdx.z];
-    // uniform early exits: smaller parity classes need fewer tiles; empty split-K slices
     const int tiles_m = (d.M + BM - 1) / BM;
     // grouped launch: the groups' m-tiles follow each other within a pixel tile (they read
     // neighbouring channels of the same pixels)
-    const int tile_all = xcd_logical_tile();
-    const int mt_all = tile_all % (tiles_m * d.groups);
-    const int grp = mt_all / tiles_m;
-    const int tile_id = (tile_all / (tiles_m * d.groups)) * tiles_m + mt_all % tiles_m;
+    // readfirstlane: the tile / group indices feed buffer descriptors, which must live in SGPRs (a
+    // descriptor the compiler cannot prove uniform costs a waterfall loop around EVERY load)
+    const int tile_all0 = __builtin_amdgcn_readfirstlane(xcd_logical_tile());
+    const ConvClass &c = d.cls[blockIdx.z];
+    // uniform early exits: smaller parity classes need fewer tiles; empty split-K slices
+    const int mt_all = tile_all0 % (tiles_m * d.groups);
+    const int grp = __builtin_amdgcn_readfirstlane(mt_all / tiles_m);   // integer division runs on the VALU
+    const int tile_id = __builtin_amdgcn_readfirstlane((tile_all0 / (tiles_m * d.groups)) * tiles_m + mt_all % tiles_m);
     if ((int)(tile_id / tiles_m) * BN >= d.B * c.OH * c.OW) return;
     const int ktiles = ktiles_of(d.Cr, c.T);
-    const int per = (ktiles + d.splitk - 1) / d.splitk;
-    if ((int)blockIdx.y * per >= ktiles) return;
+    const int slices = d.cls_splitk[blockIdx.z];
+    const int per = (ktiles + slices - 1) / slices;
+    const int kb = blockIdx.y * per;
+    if ((int)blockIdx.y >= slices || kb >= ktiles) return;
     if (threadIdx.x < 25) stab[threadIdx.x] = c.tab[threadIdx.x];
     __syncthreads();
-    const bool scale = d.in_scale != nullptr;
-    if constexpr (KMAX == 26) {  // 5x5 (never modulated)
-        modconv_body<BM, BN, 25, true, false>(d, c, As, Bs, stab, tile_id, grp);
-        return;
-    } else
-    switch (c.T) {  // compile-time tap count; no partial-tile checks when the channels fill the K tiles
-    case 9:
-        if (d.Cr % 2) {
-            if (scale) modconv_body<BM, BN, 9, true, true>(d, c, As, Bs, stab, tile_id, grp);
-            else modconv_body<BM, BN, 9, true, false>(d, c, As, Bs, stab, tile_id, grp);
-        } else {
-            if (scale) modconv_body<BM, BN, 9, false, true>(d, c, As, Bs, stab, tile_id, grp);
-            else modconv_body<BM, BN, 9, false, false>(d, c, As, Bs, stab, tile_id, grp);
-        }
-        break;
-    case 16:  // 4x4 (never modulated)
-        modconv_body<BM, BN, 16, true, false>(d, c, As, Bs, stab, tile_id, grp);
-        break;
-    case 4:
-        if (d.Cr % 4) {
-            if (scale) modconv_body<BM, BN, 4, true, true>(d, c, As, Bs, stab, tile_id, grp);
-            else modconv_body<BM, BN, 4, true, false>(d, c, As, Bs, stab, tile_id, grp);
-        } else {
-            if (scale) modconv_body<BM, BN, 4, false, true>(d, c, As, Bs, stab, tile_id, grp);
-            else modconv_body<BM, BN, 4, false, false>(d, c, As, Bs, stab, tile_id, grp);
-        }
-        break;
-    case 2:
-        if (d.Cr % 8) {
-            if (scale) modconv_body<BM, BN, 2, true, true>(d, c, As, Bs, stab, tile_id, grp);
-            else modconv_body<BM, BN, 2, true, false>(d, c, As, Bs, stab, tile_id, grp);
-        } else {
-            if (scale) modconv_body<BM, BN, 2, false, true>(d, c, As, Bs, stab, tile_id, grp);
-            else modconv_body<BM, BN, 2, false, false>(d, c, As, Bs, stab, tile_id, grp);
-        }
-        break;
-    default:
-        if (d.Cr % 16) {
-            if (scale) modconv_body<BM, BN, 1, true, true>(d, c, As, Bs, stab, tile_id, grp);
-            else modconv_body<BM, BN, 1, true, false>(d, c, As, Bs, stab, tile_id, grp);
-        } else {
-            if (scale) modconv_body<BM, BN, 1, false, true>(d, c, As, Bs, stab, tile_id, grp);
-            else modconv_body<BM, BN, 1, false, false>(d, c, As, Bs, stab, tile_id, grp);
-        }
-        break;
-    }
+    modconv_segment<BM, BN, KMAX>(d, c, As, Bs, stab, tile_id, grp, kb, min(ktiles, kb + per), slices > 1);
 }
 
 
@@ -747,19 +736,28 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
     if (tuned_splitk > 0) splitk = tuned_splitk;
     if (g_force_splitk > 0) splitk = g_force_splitk;
     splitk = std::max(1, std::min(splitk, kt_min));
+    dim3 grid(tiles, splitk, d.ncls);
     // A bias / activation epilogue needs the complete sum: with split-K it runs as a second,
     // elementwise launch (g2s_fused_bias_act in place) after the partial sums have been added.
-    const bool deferred_epilogue = splitk > 1 && (bias != nullptr || act != 0);
+    const bool split = splitk > 1;
+    const bool deferred_epilogue = split && (bias != nullptr || act != 0);
     if (deferred_epilogue) {
         d.bias = nullptr;
         d.act = 0;
     }
     d.splitk = splitk;
-    if ((splitk > 1 || holes) && !y_is_zero) {
+    // the polyphase classes of a strided scatter differ in depth (4 / 2 / 2 / 1 taps of a 3x3):
+    // slices in proportion, so that every workgroup carries about the same run of K tiles
+    int kt_max = 1;
+    for (int i = 0; i < d.ncls; i++) kt_max = std::max(kt_max, ktiles_of(d.Cr, d.cls[i].T));
+    for (int i = 0; i < d.ncls; i++) {
+        const int kt = ktiles_of(d.Cr, d.cls[i].T);
+        d.cls_splitk[i] = std::max(1, std::min(kt, (int)(((long)splitk * kt + kt_max / 2) / kt_max)));
+    }
+    if ((split || holes) && !y_is_zero) {
         if (hipMemsetAsync(y, 0, (size_t)B * d.My * d.OHf * d.OWf * sizeof(float), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
     }
-    dim3 grid(tiles, splitk, d.ncls);
     if (f16_operands) {
         for (int i = 0; i < d.ncls; i++)
             G2S_REQUIRE(d.cls[i].T == 1 || d.cls[i].T == 2 || d.cls[i].T == 4 || d.cls[i].T == 9,

@@ -26,6 +26,66 @@ def T(a):
 
 
 # ----------------------------------------------------------------------------- C ABI
+def _gfx950_code_objects(so_path):
+    """The device code objects inside libg2s.so: section .hip_fatbin is a sequence of clang offload
+    bundles (magic, entry count, then {offset, size, id length, id} per entry)."""
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    objcopy = shutil.which("objcopy")
+    if objcopy is None:
+        pytest.skip("objcopy not available")
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([objcopy, "-O", "binary", "--only-section=.hip_fatbin", so_path, fat], check=True)
+        blob = open(fat, "rb").read()
+    magic, pos, out = b"__CLANG_OFFLOAD_BUNDLE__", 0, []
+    while (i := blob.find(magic, pos)) >= 0:
+        (count,) = struct.unpack_from("<Q", blob, i + 24)
+        p = i + 32
+        for _ in range(count):
+            off, size, idlen = struct.unpack_from("<QQQ", blob, p)
+            ident = blob[p + 24:p + 24 + idlen].decode()
+            p += 24 + idlen
+            if "gfx950" in ident and size:
+                out.append(blob[i + off:i + off + size])
+        pos = i + len(magic)
+    return out
+
+
+def test_mfma_kernels_keep_buffer_descriptors_in_sgprs():
+    """A buffer descriptor the compiler cannot prove wave-uniform turns EVERY load that uses it into
+    a waterfall loop (v_readfirstlane x4, compare, s_and_saveexec, load, s_xor exec, branch) — the K
+    loop of the convolution kernels then runs at half speed without any test failing.  Disassemble
+    the shipped code objects and require that no buffer load sits inside such a loop."""
+    import subprocess
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    objs = _gfx950_code_objects(lib.LIB_PATH)
+    assert len(objs) >= 10
+    checked = 0
+    for blob in objs:
+        with tempfile.NamedTemporaryFile(suffix=".o") as f:
+            f.write(blob)
+            f.flush()
+            asm = subprocess.run([objdump, "-d", f.name], check=True, capture_output=True, text=True).stdout
+        lines = asm.splitlines()
+        kernel = None
+        for n, line in enumerate(lines):
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                kernel = m.group(1)
+                checked += any(k in kernel for k in ("modconv_kernel", "wino_kernel", "conv_wgrad_kernel"))
+            if "s_xor_b64 exec, exec" in line:
+                window = " ".join(lines[max(0, n - 3):n])
+                assert "buffer_load" not in window and "global_load" not in window, \
+                    f"waterfall loop around a load in {kernel}: {window}"
+    assert checked >= 8   # the MFMA kernel instances were among the disassembled symbols
+
+
 def test_abi_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "g2s.h")).read()
     declared = set(re.findall(r"\b(g2s_[a-z0-9_]+)\s*\(", header))
