@@ -26,5 +26,6 @@ echo "[6] micro-benchmarks"
 python3 $R/tools/bench_raster.py > $O/raster_microbench.txt 2>&1
 python3 $R/tools/conv_census.py > $O/conv_census.txt 2>&1 || true
 python3 $R/tools/bench_wino.py 1 -256 > $O/wino_microbench.txt 2>&1 || true
+python3 $R/bench.py --workload face256_fp16 --no-cpu-baseline > $O/bench_face256_fp16.json 2> $O/bench_face256_fp16.err || true
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 echo done
