@@ -597,10 +597,10 @@ static const TunedConv kTuned[] = {
     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
 // ... and of g2s_conv2d (the trained nets' layers): keyed by the call signature of g2s_conv2d.
-struct TunedConv2d { int B, Cr, M, H, k, stride, pad, adjoint, m_major, fused, tile, splitk; };
+struct TunedConv2d { int B, Cr, M, H, k, stride, pad, adjoint, m_major, fused, groups, tile, splitk; };
 static const TunedConv2d kTuned2d[] = {
 #include "conv2d_tuned.inc"
-    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
 // g2s_modconv_tune: per-thread override of the tile / split-K heuristic (tools/tune_modconv.py).
 static thread_local int g_force_tile = -1, g_force_splitk = -1;
@@ -841,11 +841,11 @@ static int conv2d_impl(const float *x, const float *w, const float *bias, float 
     G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
     ConvGeom g{k, stride, pad, adjoint ? 1 : 0, w_m_major ? 1 : 0, adjoint ? out_h : 0, adjoint ? out_w : 0};
     int tile = -1, splitk = -1;
-    if (H == W && groups == 1)
+    if (H == W)
         for (const TunedConv2d *t = kTuned2d; t->B; ++t)
             if (t->B == B && t->Cr == Cr && t->M == M && t->H == H && t->k == k && t->stride == stride &&
                 t->pad == pad && t->adjoint == g.adjoint && t->m_major == g.m_major &&
-                t->fused == (bias != nullptr || act != 0)) {
+                t->fused == (bias != nullptr || act != 0) && t->groups == groups) {
                 tile = t->tile;
                 splitk = t->splitk;
                 break;
