@@ -504,35 +504,45 @@ def test_joint_trainer_data_parallel_two_ranks_on_gpu():
     assert abs(s0 - s1) <= 1e-6 * a0 and abs(a0 - a1) <= 1e-6 * a0
 
 
-@pytest.mark.parametrize("image_size,gan_size,cm,prior,n_proj", [
-    (64, 64, 1, "ellipsoid", 2),          # BASELINE config 1 (minimal_config restated at 64x64), on the GPU
-    (128, 256, 1, "smoothed_box", 4),     # config 3 (cat)
-    (128, 512, 2, "ellipsoid", 2)])       # config 4 (car)
-def test_other_baseline_configs_run(image_size, gan_size, cm, prior, n_proj):
+@pytest.mark.parametrize("image_size,gan_size,cm,prior,n_proj,joint", [
+    (64, 64, 1, "ellipsoid", 2, False),         # BASELINE config 1 (minimal_config restated at 64x64), on the GPU
+    (128, 256, 1, "smoothed_box", 16, False),   # config 3 (cat: configs/cat.yml, n_proj_samples 16)
+    (128, 512, 2, "ellipsoid", 8, True)])       # config 4 (car: configs/car.yml, joint training)
+def test_other_baseline_configs_run(image_size, gan_size, cm, prior, n_proj, joint):
     """BASELINE configs 1 / 3 / 4.  Config 1: the minimal single-image 64x64 run (ellipsoid prior, one
     stage; SURVEY §8d — the reference's OffsetEncoder(64) cannot be constructed, ours emits 512
-    channels) as GPU plumbing: 2 prior pre-training steps + one iteration of each kind.  Configs 3 /
-    4 (cat: gan_size 256, smoothed-box prior; car: gan_size 512, channel multiplier 2): G output is
-    area-resized to 128.  Finite losses, every trained net moves."""
+    channels) as GPU plumbing: 2 prior pre-training steps + one iteration of each kind.  Config 3
+    (cat: gan_size 256, smoothed-box prior, 16 projected samples): instance trainer.  Config 4 (car:
+    gan_size 512, channel multiplier 2, 8 projected samples): the joint trainer
+    (GeneralizingTrainer2, trainer.py:338-479) on two images — its one-rank form; the gradient
+    all-reduce of the 8-GPU form is covered by the gloo tests.  G output is area-resized to 128.
+    Finite losses, every trained net moves."""
     import bench
     from gan2shape_amd.model import GAN2Shape
-    from gan2shape_amd.trainer import Trainer
+    from gan2shape_amd.trainer import GeneralizingTrainer2, Trainer
     dev = torch.device("cuda")
     cfg = bench.face_config(n_proj=n_proj)
     cfg.update(image_size=image_size, gan_size=gan_size, channel_multiplier=cm, prior_name=prior,
-               n_epochs_prior=2 if image_size == 64 else 1,
+               n_epochs_prior=2 if image_size == 64 else 1, n_epochs_generalized=1,
                category={64: "face", 256: "cat", 512: "car"}[gan_size])
     torch.manual_seed(0)
-    t = Trainer(GAN2Shape, cfg, device=dev)
+    t = (GeneralizingTrainer2 if joint else Trainer)(GAN2Shape, cfg, device=dev)
     g = torch.Generator().manual_seed(7)
-    image = torch.tanh(torch.nn.functional.interpolate(torch.randn(1, 3, image_size // 4, image_size // 4, generator=g),
-                                                       scale_factor=4, mode="bilinear")).to(dev)
-    with torch.no_grad():
-        latent = t.model.generator.style_forward(torch.randn(1, 512, generator=g).to(dev))
+    data = []
+    for i in range(2 if joint else 1):
+        image = torch.tanh(torch.nn.functional.interpolate(
+            torch.randn(1, 3, image_size // 4, image_size // 4, generator=g), scale_factor=4, mode="bilinear")).to(dev)
+        with torch.no_grad():
+            latent = t.model.generator.style_forward(torch.randn(1, 512, generator=g).to(dev))
+        data.append((image[0].cpu(), latent[0].cpu(), i))
     before = {n: p.detach().clone() for n, p in t.model.named_parameters() if p.requires_grad}
-    n = t.fit([(image[0].cpu(), latent[0].cpu(), 0)], stages=[{'step1': 1, 'step2': 1, 'step3': 1}])
-    assert n == 3
-    assert all(math.isfinite(h[3]) for h in t.history) and len(t.history) == 3
+    if joint:
+        n = t.fit(data, stages=[{'step1': 1, 'step2': 1, 'step3': 1}], batch_size=2)
+        assert n == 1 + 2 * (1 + 1) and len(t.history) == 1 + 2 * 2
+    else:
+        n = t.fit(data, stages=[{'step1': 1, 'step2': 1, 'step3': 1}])
+        assert n == 3 and len(t.history) == 3
+    assert all(h[3] is None or math.isfinite(h[3]) for h in t.history)
     moved = {k.split('.')[0] for k, p in t.model.named_parameters() if k in before and not torch.equal(before[k], p.detach())}
     assert {'depth_net', 'albedo_net', 'viewpoint_net', 'lighting_net', 'offset_encoder_net'} <= moved
 
