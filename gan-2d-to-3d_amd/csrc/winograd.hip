@@ -29,8 +29,12 @@
 //     registers (the 16 positions of one (channel, tile) live in one lane) and feeds the
 //     demodulation / bias / activation epilogue; outputs leave as float2 rows.
 //   * K tile = 4 channels = 32 MFMAs per wave (2048 matrix-pipe cycles); the staging of tile t+1
-//     and the loads of tile t+2 are issued between those MFMAs; LDS double-buffered, one barrier
-//     per K tile.
+//     and the loads of tile t+2 are issued between those MFMAs, one hand-placed slice per MFMA gap
+//     (one wave per SIMD issues in order: whatever is not between two MFMAs stalls the matrix pipe);
+//     V double-buffered in LDS, U in a ring of three (its DMA runs two tiles ahead), one raw
+//     s_barrier per K tile.
+//   * Partition: whole tiles, split-K, or stream-K (equal runs of (tile, K tile) units over 256
+//     workgroups, a run may cross tile borders; partial sums meet by float atomics in a cleared y).
 #include <algorithm>
 #include "g2s_common.h"
 #include "xcd_tile.h"
