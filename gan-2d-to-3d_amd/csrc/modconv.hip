@@ -21,6 +21,7 @@
 // multiplications by inserted zeros; classes are blockIdx.z of one launch.
 // Small layers (4x4 .. 16x16) use 64x64 tiles and split-K with float atomics to fill 256 CUs.
 #include "g2s_common.h"
+#include "conv_wgrad_core.h"
 #include "xcd_tile.h"
 
 namespace g2s {
@@ -348,31 +349,73 @@ __device__ __forceinline__ void modconv_segment(const ConvDesc &d, const ConvCla
 #undef G2S_BODY
 }
 
+// One workgroup of the convolution: bx = workgroup within the grid row of nx (XCD-aware tile order),
+// by = split-K slice, bz = polyphase class; row = by + ny * bz.
 template <int BM, int BN, int KMAX>
-__global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
-    __shared__ float As[2][KMAX][BM + 1];
-    __shared__ float Bs[2][KMAX + 1][BN];
-    __shared__ int stab[25];
+__device__ __forceinline__ void modconv_block(const ConvDesc &d, float (&As)[2][KMAX][BM + 1],
+                                              float (&Bs)[2][KMAX + 1][BN], int (&stab)[25], const int nx,
+                                              const int bx, const int by, const int bz, const int row) {
     const int tiles_m = (d.M + BM - 1) / BM;
     // grouped launch: the groups' m-tiles follow each other within a pixel tile (they read
     // neighbouring channels of the same pixels)
     // readfirstlane: the tile / group indices feed buffer descriptors, which must live in SGPRs (a
     // descriptor the compiler cannot prove uniform costs a waterfall loop around EVERY load)
-    const int tile_all0 = __builtin_amdgcn_readfirstlane(xcd_logical_tile());
-    const ConvClass &c = d.cls[blockIdx.z];
+    const int tile_all0 = __builtin_amdgcn_readfirstlane(xcd_logical_tile(nx, bx, row));
+    const ConvClass &c = d.cls[bz];
     // uniform early exits: smaller parity classes need fewer tiles; empty split-K slices
     const int mt_all = tile_all0 % (tiles_m * d.groups);
     const int grp = __builtin_amdgcn_readfirstlane(mt_all / tiles_m);   // integer division runs on the VALU
     const int tile_id = __builtin_amdgcn_readfirstlane((tile_all0 / (tiles_m * d.groups)) * tiles_m + mt_all % tiles_m);
     if ((int)(tile_id / tiles_m) * BN >= d.B * c.OH * c.OW) return;
     const int ktiles = ktiles_of(d.Cr, c.T);
-    const int slices = d.cls_splitk[blockIdx.z];
+    const int slices = d.cls_splitk[bz];
     const int per = (ktiles + slices - 1) / slices;
-    const int kb = blockIdx.y * per;
-    if ((int)blockIdx.y >= slices || kb >= ktiles) return;
+    const int kb = by * per;
+    if (by >= slices || kb >= ktiles) return;
     if (threadIdx.x < 25) stab[threadIdx.x] = c.tab[threadIdx.x];
     __syncthreads();
     modconv_segment<BM, BN, KMAX>(d, c, As, Bs, stab, tile_id, grp, kb, min(ktiles, kb + per), slices > 1);
+}
+
+template <int BM, int BN, int KMAX>
+__global__ __launch_bounds__(NTHREADS) void modconv_kernel(ConvDesc d) {
+    __shared__ float As[2][KMAX][BM + 1];
+    __shared__ float Bs[2][KMAX + 1][BN];
+    __shared__ int stab[25];
+    modconv_block<BM, BN, KMAX>(d, As, Bs, stab, gridDim.x, blockIdx.x, blockIdx.y, blockIdx.z,
+                                blockIdx.y + gridDim.y * blockIdx.z);
+}
+
+// The weight-gradient GEMM alone (fallback of g2s_conv2d_bwd when the data-gradient takes a 128-wide tile).
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_rider_kernel(WgradParams p) {
+    __shared__ float Wa[WG_BK][WG_BM + 1];
+    __shared__ float Wb[WG_BK][WG_BN + 1];
+    wgrad_block(p, Wa, Wb, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Backward of one layer of the trained nets in ONE grid: workgroups [0, n_dgrad) run the
+// data-gradient (the convolution kernel, 64x64 tiles), the rest the weight-gradient GEMM
+// (conv_wgrad_core.h).  Both are latency-bound at these sizes (10-25 us each for a few hundred
+// workgroups): dealt to the CUs together, the layer costs the longer of the two, and one graph node.
+// The flattened workgroup order equals that of the two stand-alone launches, so the XCD-aware tile
+// order of the convolution is unchanged.
+template <int KMAX>
+__global__ __launch_bounds__(NTHREADS) void conv_bwd_kernel(ConvDesc d, WgradParams p, int nx, int ny, int n_dgrad,
+                                                            int w_tiles, int w_split) {
+    __shared__ float As[2][KMAX][64 + 1];
+    __shared__ float Bs[2][KMAX + 1][64];
+    __shared__ int stab[25];
+    __shared__ float Wa[WG_BK][WG_BM + 1];
+    __shared__ float Wb[WG_BK][WG_BN + 1];
+    const int lin = blockIdx.x;
+    if (lin < n_dgrad) {
+        const int bx = lin % nx, row = lin / nx;
+        modconv_block<64, 64, KMAX>(d, As, Bs, stab, nx, bx, row % ny, row / ny, row);
+    } else {
+        const int l = lin - n_dgrad;
+        const int bx = l % w_tiles, r = l / w_tiles;
+        wgrad_block(p, Wa, Wb, bx, r % w_split, r / w_split);
+    }
 }
 
 
@@ -623,10 +666,18 @@ struct ConvGeom {
     int out_h, out_w;  // adjoint only; 0 = (H-1)*s - 2p + k
 };
 
+// The weight-gradient GEMM that rides in the same grid as a data-gradient launch (g2s_conv2d_bwd).
+struct WgradRider {
+    WgradParams p;
+    int tiles, split;
+    bool dw_is_zero;
+};
+
 static int conv_launch(const float *x, const float *w, const float *in_scale, const float *out_scale,
                        const float *bias, int act, float act_alpha, float act_gain, float *y, int B,
                        int Cr, int M, int H, int W, const ConvGeom &g, int tuned_tile, int tuned_splitk,
-                       g2s_stream_t stream, bool y_is_zero = false, bool f16_operands = false, int groups = 1) {
+                       g2s_stream_t stream, bool y_is_zero = false, bool f16_operands = false, int groups = 1,
+                       const WgradRider *rider = nullptr) {
     G2S_REQUIRE(x && w && y, "x, w, y must not be NULL");
     G2S_REQUIRE(B > 0 && Cr > 0 && M > 0 && H > 0 && W > 0, "sizes must be positive");
     const int k = g.k, s_ = g.stride, p_ = g.pad, KK = k * k;
@@ -764,6 +815,27 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
                         "fp16 operands: 1x1 / 3x3 kernels (stride 1 or 2) only");
         if (pick == 2) modconv_f16_kernel<64, 64><<<grid, NTHREADS, 0, st>>>(d);
         else modconv_f16_kernel<128, 128><<<grid, NTHREADS, 0, st>>>(d);
+    } else if (rider) {
+        // data-gradient + weight-gradient of one layer in one grid (64x64 tiles: what the trained
+        // nets' layers use); any other tile: two launches
+        const WgradParams &p = rider->p;
+        if (p.atomic && !rider->dw_is_zero &&
+            hipMemsetAsync(p.dw, 0, (size_t)p.groups * p.Ca * p.N * sizeof(float), st) != hipSuccess)
+            return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(dw) failed");
+        if (pick == 2) {
+            const int n_dgrad = tiles * splitk * d.ncls, n_wgrad = rider->tiles * rider->split * p.groups;
+            if (big) conv_bwd_kernel<26><<<n_dgrad + n_wgrad, NTHREADS, 0, st>>>(d, p, tiles, splitk, n_dgrad, rider->tiles, rider->split);
+            else conv_bwd_kernel<18><<<n_dgrad + n_wgrad, NTHREADS, 0, st>>>(d, p, tiles, splitk, n_dgrad, rider->tiles, rider->split);
+        } else {
+            if (big) {
+                if (pick == 0) modconv_kernel<128, 128, 26><<<grid, NTHREADS, 0, st>>>(d);
+                else modconv_kernel<128, 64, 26><<<grid, NTHREADS, 0, st>>>(d);
+            } else {
+                if (pick == 0) modconv_kernel<128, 128, 18><<<grid, NTHREADS, 0, st>>>(d);
+                else modconv_kernel<128, 64, 18><<<grid, NTHREADS, 0, st>>>(d);
+            }
+            conv_wgrad_rider_kernel<<<dim3(rider->tiles, rider->split, p.groups), NTHREADS, 0, st>>>(p);
+        }
     } else if (big) {
         if (pick == 0) modconv_kernel<128, 128, 26><<<grid, NTHREADS, 0, st>>>(d);
         else if (pick == 1) modconv_kernel<128, 64, 26><<<grid, NTHREADS, 0, st>>>(d);
@@ -837,7 +909,8 @@ extern "C" int g2s_conv_bias_act(const float *x, const float *w, const float *bi
 
 static int conv2d_impl(const float *x, const float *w, const float *bias, float *y, int B, int Cr, int M, int H,
                        int W, int k, int stride, int pad, int adjoint, int w_m_major, int out_h, int out_w,
-                       int act, float alpha, float gain, int y_is_zero, int groups, g2s_stream_t stream) {
+                       int act, float alpha, float gain, int y_is_zero, int groups, g2s_stream_t stream,
+                       const WgradRider *rider = nullptr) {
     G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
     ConvGeom g{k, stride, pad, adjoint ? 1 : 0, w_m_major ? 1 : 0, adjoint ? out_h : 0, adjoint ? out_w : 0};
     int tile = -1, splitk = -1;
@@ -851,7 +924,7 @@ static int conv2d_impl(const float *x, const float *w, const float *bias, float 
                 break;
             }
     return conv_launch(x, w, nullptr, nullptr, bias, act, alpha, gain, y, B, Cr, M, H, W, g, tile, splitk, stream,
-                       y_is_zero != 0, false, groups);
+                       y_is_zero != 0, false, groups, rider);
 }
 
 extern "C" int g2s_conv2d(const float *x, const float *w, const float *bias, float *y, int B, int Cr,
@@ -868,4 +941,17 @@ extern "C" int g2s_conv2d_grouped(const float *x, const float *w, const float *b
                                   int groups, g2s_stream_t stream) {
     return conv2d_impl(x, w, bias, y, B, Cr, M, H, W, k, stride, pad, adjoint, w_m_major, out_h, out_w, act, alpha,
                        gain, y_is_zero, groups, stream);
+}
+
+extern "C" int g2s_conv2d_bwd(const float *gy, const float *w, float *gx, int B, int Cr, int M, int H, int W, int k,
+                              int stride, int pad, int adjoint, int w_m_major, int out_h, int out_w, int gx_is_zero,
+                              const float *A, const float *G, float *dw, int Ca, int Cg, int PH, int PW, int GH,
+                              int GW, int dw_is_zero, int groups, g2s_stream_t stream) {
+    WgradRider rider;
+    const int rc = wgrad_plan(A, G, dw, B, Ca, Cg, PH, PW, GH, GW, k, stride, pad, groups, rider.p, rider.tiles,
+                              rider.split);
+    if (rc != G2S_OK) return rc;
+    rider.dw_is_zero = dw_is_zero != 0;
+    return conv2d_impl(gy, w, nullptr, gx, B, Cr, M, H, W, k, stride, pad, adjoint, w_m_major, out_h, out_w, 0, 0.0f,
+                       1.0f, gx_is_zero, groups, stream, &rider);
 }

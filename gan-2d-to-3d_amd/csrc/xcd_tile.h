@@ -8,9 +8,9 @@ namespace g2s {
 // The M-tiles of one pixel tile all read the same im2col operand: give every XCD a CONTIGUOUS range
 // of logical tiles (M-tile fastest), so that those workgroups share one L2 instead of fetching the
 // operand once per XCD.  Returns the logical tile of this workgroup within its (y, z) grid row.
-__device__ __forceinline__ int xcd_logical_tile() {
-    const int n = gridDim.x, bx = blockIdx.x;
-    const int row = blockIdx.y + gridDim.y * blockIdx.z;
+// n = workgroups per grid row, bx = index within the row, row = index of the row in the launch
+// (rows follow each other in the flattened workgroup order the hardware deals to the XCDs).
+__device__ __forceinline__ int xcd_logical_tile(const int n, const int bx, const int row) {
     const int off = (n * row) & 7;           // XCD of block 0 of this row
     const int x = (bx + off) & 7;            // XCD this workgroup runs on
     int start = 0;
@@ -20,6 +20,10 @@ __device__ __forceinline__ int xcd_logical_tile() {
     }
     const int f = (x - off) & 7;             // first block of this row on XCD x
     return start + ((bx - f) >> 3);
+}
+
+__device__ __forceinline__ int xcd_logical_tile() {
+    return xcd_logical_tile(gridDim.x, blockIdx.x, blockIdx.y + gridDim.y * blockIdx.z);
 }
 
 }  // namespace g2s

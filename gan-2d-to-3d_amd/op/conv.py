@@ -112,6 +112,29 @@ def _wgrad(A, G, k, stride, pad, out=None, groups=1):
     return dw
 
 
+def _conv_bwd_raw(gy, w, x, cin, cout, k, stride, pad, transposed, gx_out=None, gw_out=None, groups=1):
+    """Data-gradient AND weight-gradient of one layer as one launch (g2s_conv2d_bwd): what
+    _conv2d_raw(gy, w, ...) and _wgrad(...) compute, their workgroups dealt to the CUs together."""
+    B, _, H, W = gy.shape
+    oh, ow = x.shape[2], x.shape[3]
+    adjoint = not transposed
+    gx = gx_out if gx_out is not None else torch.empty((B, groups * cin, oh, ow), dtype=torch.float32, device=gy.device)
+    A, G = (x, gy) if transposed else (gy, x)
+    Ca, Cg = A.shape[1] // groups, G.shape[1] // groups
+    dw = gw_out if gw_out is not None else torch.empty((groups * Ca, Cg, k, k), dtype=torch.float32, device=gy.device)
+    L = _lib.load()
+    from gan2shape_amd.modconv import profiled
+    sp = H * W if adjoint else oh * ow
+    flop = 2.0 * B * groups * cout * cin * k * k * sp + 2.0 * B * groups * Ca * Cg * k * k * A.shape[2] * A.shape[3]
+    with profiled(flop, 4.0 * (2 * gy.numel() + w.numel() + gx.numel() + x.numel() + dw.numel())):
+        _lib.check(L.g2s_conv2d_bwd(_lib.ptr(gy), _lib.ptr(w), _lib.ptr(gx), B, cout, cin, H, W, k, stride, pad,
+                                    int(adjoint), int(transposed), oh if adjoint else 0, ow if adjoint else 0,
+                                    int(gx_out is not None), _lib.ptr(A), _lib.ptr(G), _lib.ptr(dw), Ca, Cg,
+                                    A.shape[2], A.shape[3], G.shape[2], G.shape[3], int(gw_out is not None),
+                                    groups, _lib.stream()))
+    return gx, dw
+
+
 class ConvFunction(Function):
     """transposed = False: F.conv2d(x, w [Cout,Cin,k,k], bias, stride, pad); True:
     F.conv_transpose2d(x, w [Cin,Cout,k,k], bias, stride, pad); then leaky-ReLU(slope) if
@@ -163,11 +186,15 @@ class ConvFunction(Function):
         cin, cout = (w.shape[0] // groups, w.shape[1]) if transposed else (w.shape[1], w.shape[0] // groups)
         gx = gw = gb = None
         arena = ctx.arena
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            gx_out = None if arena is None else arena.take_bwd(tuple(x.shape))
+            gw_out = None if arena is None else arena.take_bwd(tuple(w.shape))
+            gx, gw = _conv_bwd_raw(gy, w, x, cin, cout, k, stride, pad, transposed, gx_out, gw_out, groups)
+        elif ctx.needs_input_grad[0]:
             out = None if arena is None else arena.take_bwd(tuple(x.shape))
             gx = _conv2d_raw(gy, w, None, cout, cin, k, stride, pad, not transposed, transposed,
                              (x.shape[2], x.shape[3]), False, 0.0, out=out, groups=groups)
-        if ctx.needs_input_grad[1]:
+        elif ctx.needs_input_grad[1]:
             out = None if arena is None else arena.take_bwd(tuple(w.shape))
             gw = (_wgrad(x, gy, k, stride, pad, out, groups) if transposed
                   else _wgrad(gy, x, k, stride, pad, out, groups))

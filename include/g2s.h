@@ -205,6 +205,20 @@ int g2s_conv2d_wgrad_grouped(const float *A, const float *G, float *dw, int B, i
                              int PW, int GH, int GW, int k, int stride, int pad, int dw_is_zero, int groups,
                              g2s_stream_t stream);
 
+/* Backward of one convolution layer of the trained nets as ONE launch: the data-gradient
+ *   g2s_conv2d[_grouped](gy, w, NULL, gx, B, Cr, M, H, W, k, stride, pad, adjoint, w_m_major, out_h, out_w,
+ *                        0, 0, 1, gx_is_zero, [groups,] stream)
+ * and the weight-gradient
+ *   g2s_conv2d_wgrad[_grouped](A, G, dw, B, Ca, Cg, PH, PW, GH, GW, k, stride, pad, dw_is_zero, [groups,] stream)
+ * of the same layer (k, stride, pad, B, groups shared) in one grid — the two are independent and
+ * latency-bound at these sizes, so the layer costs the longer of the two.  Results are those of
+ * the two separate calls.  (torch's ConvolutionBackward of nn.Conv2d / nn.ConvTranspose2d,
+ * GAN2Shape/networks.py:23-244.) */
+int g2s_conv2d_bwd(const float *gy, const float *w, float *gx, int B, int Cr, int M, int H, int W, int k,
+                   int stride, int pad, int adjoint, int w_m_major, int out_h, int out_w, int gx_is_zero,
+                   const float *A, const float *G, float *dw, int Ca, int Cg, int PH, int PW, int GH, int GW,
+                   int dw_is_zero, int groups, g2s_stream_t stream);
+
 /* fp16-OPERAND form of g2s_modconv / g2s_conv_bias_act (BASELINE config 5, "fp16 MFMA path"): same
  * arguments and geometry; x, w, y stay fp32 in memory, both GEMM operands are rounded to fp16 on
  * their way into LDS and multiplied by v_mfma_f32_32x32x8_f16 with fp32 accumulation.  bias (NULL ok)

@@ -426,6 +426,39 @@ def test_conv_function_matches_torch_f64(g2s, B, cin, cout, H, k, stride, pad, t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,groups,cin,cout,H,k,stride,pad,transposed", [
+    (1, 2, 64, 128, 32, 4, 2, 1, False), (1, 2, 128, 64, 8, 4, 2, 1, True), (1, 2, 32, 32, 64, 5, 1, 2, False),
+    (9, 2, 128, 256, 16, 4, 2, 1, False), (8, 1, 128, 128, 16, 3, 1, 1, False), (2, 1, 5, 7, 11, 3, 2, 1, False),
+])
+def test_fused_backward_launch_equals_the_two_launches(g2s, B, groups, cin, cout, H, k, stride, pad, transposed):
+    """g2s_conv2d_bwd (data-gradient + weight-gradient of one layer in one grid) against
+    g2s_conv2d[_grouped] + g2s_conv2d_wgrad[_grouped], with the data-gradient on its 64x64 tile (one
+    grid) and forced onto the 128-wide tiles (the entry point then launches the two kernels itself)."""
+    from gan2shape_amd import lib
+    from gan2shape_amd.op.conv import _conv2d_raw, _conv_bwd_raw, _wgrad
+    L = lib.load()
+    torch.manual_seed(B + cin + H)
+    x = torch.randn(B, groups * cin, H, H, device="cuda")
+    w = torch.randn((groups * cin, cout, k, k) if transposed else (groups * cout, cin, k, k), device="cuda") / (cin * k * k) ** 0.5
+    y = _conv2d_raw(x, w, None, cin, cout, k, stride, pad, transposed, not transposed, None, False, 0.0, groups=groups)
+    gy = torch.randn_like(y)
+    try:
+        L.g2s_modconv_tune(2, 1)   # unsplit reference
+        gx_ref = _conv2d_raw(gy, w, None, cout, cin, k, stride, pad, not transposed, transposed, (H, H), False, 0.0,
+                             groups=groups)
+        gw_ref = _wgrad(x, gy, k, stride, pad, None, groups) if transposed else _wgrad(gy, x, k, stride, pad, None, groups)
+        for tile, sk in [(-1, -1), (2, 1), (2, 3), (1, 1), (0, 2)]:
+            L.g2s_modconv_tune(tile, sk)
+            gx, gw = _conv_bwd_raw(gy, w, x, cin, cout, k, stride, pad, transposed, None, None, groups)
+            assert gx.shape == x.shape and gw.shape == w.shape
+            for got, want, what in ((gx, gx_ref, "gx"), (gw, gw_ref, "gw")):
+                err = float((got - want).norm())
+                assert err <= 1e-5 * float(want.norm()) + 1e-7, (tile, sk, what, err, float(want.norm()))
+    finally:
+        L.g2s_modconv_tune(-1, -1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["DepthNet", "AlbedoNet", "ViewpointNet", "LightingNet", "OffsetEncoder"])
 def test_trained_nets_fused_match_modules(g2s, name):
     """Each trained net on the GPU (libg2s convolutions + fused GroupNorm) equals its own module
