@@ -524,7 +524,8 @@ def main():
                     "mfma_executed": {"achieved": executed, "frac": executed / F32_MFMA_PEAK_TFLOPS},
                     "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": (sum(p[3] for p in prof) / len(prof)) if prof else None,
-                    "kernel": "the fp32-MFMA convolution kernels g2s::modconv_kernel (direct implicit GEMM) + "
+                    "kernel": "the fp32-MFMA convolution kernels g2s::modconv_kernel (direct implicit GEMM; with "
+                              "g2s::conv_bwd_kernel, the same body next to the weight-gradient GEMM of a layer) + "
                               "g2s::wino_kernel (Winograd F(2x2,3x3)): every launch of the 20-step cycle — "
                               "generator, discriminator, VGG and the small trained nets",
                     "per_kernel": per_kernel,

@@ -13,7 +13,7 @@ assert len(marks) >= 2, f"need two marker kernels, found {len(marks)}"
 rows = rows[marks[0] + 1:marks[1]]
 span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e6
 cats = collections.OrderedDict([
-    ("g2s modconv (MFMA implicit GEMM)", ("modconv_kernel",)), ("g2s winograd (MFMA F(2x2,3x3))", ("wino_kernel",)), ("g2s upfirdn2d", ("upfirdn2d",)),
+    ("g2s modconv (MFMA implicit GEMM)", ("modconv_kernel", "conv_bwd_kernel")), ("g2s winograd (MFMA F(2x2,3x3))", ("wino_kernel",)), ("g2s upfirdn2d", ("upfirdn2d",)),
     ("g2s bias/act", ("fba_", "noise_bias")), ("g2s raster", ("raster_",)),
     ("g2s geometry/shading/lpips/rowops", ("g2s::",)),
     ("MIOpen conv (winograd/igemm/gemm)", ("miopenSp3", "igemm_", "Cijk_", "gemm", "Im2d2Col", "Col2Im", "naive_conv", "MIOpen", "conv")),
