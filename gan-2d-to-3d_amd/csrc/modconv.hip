@@ -84,12 +84,15 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
                                              const int (&stab)[25], const int tile_id, const int grp,
                                              const int kt_begin, const int kt_end, const bool atomic) {
     constexpr int BKT = KTile<T>::BKT, CPT = KTile<T>::CPT, BK_MAX = KTile<T>::KMAX;
-    constexpr int WMT = BM / 64, WNT = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
+    // 4 waves: 2 x 2 over the tile, or 1 x 4 for the 32-row tile (layers of <= 32 output channels
+    // would leave half of a 64-row tile's matrix work on padding); 32x32 MFMA tiles per wave
+    constexpr int WAVES_M = BM >= 64 ? 2 : 1, WAVES_N = 4 / WAVES_M;
+    constexpr int WMT = BM / (32 * WAVES_M), WNT = BN / (32 * WAVES_N);
     constexpr bool WIDE = (T == 9);              // 9 contiguous taps per (m, channel): 3 x dwordx3
     constexpr int EA = WIDE ? (BM * 6 + NTHREADS - 1) / NTHREADS : (BM * BKT + NTHREADS - 1) / NTHREADS;
     constexpr int EB = (BN * BKT + NTHREADS - 1) / NTHREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int Ncls = d.B * c.OH * c.OW;
     const int tiles_m = (d.M + BM - 1) / BM;
     const int m0 = (tile_id % tiles_m) * BM;
@@ -237,17 +240,17 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
         float(*bnext)[BN] = Bs[cur ^ 1];
         float a[2][WMT], b[2][WNT];
 #pragma unroll
-        for (int i = 0; i < WMT; i++) a[0][i] = As[cur][lk][wm * (BM / 2) + i * 32 + l31];
+        for (int i = 0; i < WMT; i++) a[0][i] = As[cur][lk][wm * (BM / WAVES_M) + i * 32 + l31];
 #pragma unroll
-        for (int j = 0; j < WNT; j++) b[0][j] = Bs[cur][lk][wn * (BN / 2) + j * 32 + l31];
+        for (int j = 0; j < WNT; j++) b[0][j] = Bs[cur][lk][wn * (BN / WAVES_N) + j * 32 + l31];
 #pragma unroll
         for (int st = 0; st < BKT / 2; st++) {
             const int p = st & 1, k2n = 2 * st + 2;
             if (st + 1 < BKT / 2) {
 #pragma unroll
-                for (int i = 0; i < WMT; i++) a[p ^ 1][i] = As[cur][k2n + lk][wm * (BM / 2) + i * 32 + l31];
+                for (int i = 0; i < WMT; i++) a[p ^ 1][i] = As[cur][k2n + lk][wm * (BM / WAVES_M) + i * 32 + l31];
 #pragma unroll
-                for (int j = 0; j < WNT; j++) b[p ^ 1][j] = Bs[cur][k2n + lk][wn * (BN / 2) + j * 32 + l31];
+                for (int j = 0; j < WNT; j++) b[p ^ 1][j] = Bs[cur][k2n + lk][wn * (BN / WAVES_N) + j * 32 + l31];
             }
             if (WIDE && st == 0) loadS(kt2, rsn);  // scales of tile kt+2, used from the next iteration on
             int slot = 0;
@@ -287,7 +290,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
     // ---- epilogue: C[m][n], m = (r&3) + 8*(r>>2) + 4*(lane>>5), n = lane&31 within a 32x32 tile
 #pragma unroll
     for (int j = 0; j < WNT; j++) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+        const int n = n0 + wn * (BN / WAVES_N) + j * 32 + l31;
         if (n >= Ncls) continue;
         const int b = n / (c.OH * c.OW);
         const int r_ = n % (c.OH * c.OW);
@@ -299,7 +302,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
         for (int i = 0; i < WMT; i++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int m = m0 + wm * (BM / WAVES_M) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (m >= d.M) continue;
                 float v = acc[i][j][r];
                 if (ob) v *= ob[m];
@@ -394,23 +397,23 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_rider_kernel(WgradParams 
 }
 
 // Backward of one layer of the trained nets in ONE grid: workgroups [0, n_dgrad) run the
-// data-gradient (the convolution kernel, 64x64 tiles), the rest the weight-gradient GEMM
+// data-gradient (the convolution kernel, 64x64 or 32x128 tiles), the rest the weight-gradient GEMM
 // (conv_wgrad_core.h).  Both are latency-bound at these sizes (10-25 us each for a few hundred
 // workgroups): dealt to the CUs together, the layer costs the longer of the two, and one graph node.
 // The flattened workgroup order equals that of the two stand-alone launches, so the XCD-aware tile
 // order of the convolution is unchanged.
-template <int KMAX>
+template <int BM, int BN, int KMAX>
 __global__ __launch_bounds__(NTHREADS) void conv_bwd_kernel(ConvDesc d, WgradParams p, int nx, int ny, int n_dgrad,
                                                             int w_tiles, int w_split) {
-    __shared__ float As[2][KMAX][64 + 1];
-    __shared__ float Bs[2][KMAX + 1][64];
+    __shared__ float As[2][KMAX][BM + 1];
+    __shared__ float Bs[2][KMAX + 1][BN];
     __shared__ int stab[25];
     __shared__ float Wa[WG_BK][WG_BM + 1];
     __shared__ float Wb[WG_BK][WG_BN + 1];
     const int lin = blockIdx.x;
     if (lin < n_dgrad) {
         const int bx = lin % nx, row = lin / nx;
-        modconv_block<64, 64, KMAX>(d, As, Bs, stab, nx, bx, row % ny, row / ny, row);
+        modconv_block<BM, BN, KMAX>(d, As, Bs, stab, nx, bx, row % ny, row / ny, row);
     } else {
         const int l = lin - n_dgrad;
         const int bx = l % w_tiles, r = l / w_tiles;
@@ -649,8 +652,8 @@ static const TunedConv2d kTuned2d[] = {
 static thread_local int g_force_tile = -1, g_force_splitk = -1;
 
 extern "C" int g2s_modconv_tune(int tile, int splitk) {
-    G2S_REQUIRE(tile >= -2 && tile <= 2 && splitk >= -1 && splitk <= 64 && splitk != 0,
-                "tile must be -1 (built-in), -2 (heuristic without the tuned table) or 0..2, "
+    G2S_REQUIRE(tile >= -2 && tile <= 3 && splitk >= -1 && splitk <= 64 && splitk != 0,
+                "tile must be -1 (built-in), -2 (heuristic without the tuned table) or 0..3, "
                 "splitk -1 (built-in) or 1..64");
     g_force_tile = tile;
     g_force_splitk = splitk;
@@ -771,12 +774,13 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
     G2S_REQUIRE(nmax < (1l << 30) && (long)B * d.Cx * H * W < (1l << 29) && (long)groups * M * Cr * KK < (1l << 29),
                 "problem too large for 32-bit byte offsets");
     hipStream_t st = as_stream(stream);
-    const int cfgs[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    const int cfgs[4][2] = {{128, 128}, {128, 64}, {64, 64}, {32, 128}};
     int pick = 2;
     for (int i = 0; i < 3; i++) {
         const long blocks = (long)groups * cdiv(d.M, cfgs[i][0]) * cdiv(nmax, cfgs[i][1]) * d.ncls;
         if (d.M > cfgs[i][0] / 2 && blocks >= 512) { pick = i; break; }
     }
+    if (d.M <= 32 && nmax >= 1024 && !f16_operands) pick = 3;   // a 64-row tile would be half padding
     if (tuned_tile >= 0 && g_force_tile != -2) pick = tuned_tile;
     else tuned_splitk = -1;
     if (g_force_tile >= 0) pick = g_force_tile;
@@ -813,19 +817,23 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
         for (int i = 0; i < d.ncls; i++)
             G2S_REQUIRE(d.cls[i].T == 1 || d.cls[i].T == 2 || d.cls[i].T == 4 || d.cls[i].T == 9,
                         "fp16 operands: 1x1 / 3x3 kernels (stride 1 or 2) only");
+        G2S_REQUIRE(pick <= 2, "fp16 operands: tiles 0..2 only");
         if (pick == 2) modconv_f16_kernel<64, 64><<<grid, NTHREADS, 0, st>>>(d);
         else modconv_f16_kernel<128, 128><<<grid, NTHREADS, 0, st>>>(d);
     } else if (rider) {
-        // data-gradient + weight-gradient of one layer in one grid (64x64 tiles: what the trained
-        // nets' layers use); any other tile: two launches
+        // data-gradient + weight-gradient of one layer in one grid (64x64 / 32x128 tiles: what the
+        // trained nets' layers use); 128-row tiles: two launches
         const WgradParams &p = rider->p;
         if (p.atomic && !rider->dw_is_zero &&
             hipMemsetAsync(p.dw, 0, (size_t)p.groups * p.Ca * p.N * sizeof(float), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(dw) failed");
-        if (pick == 2) {
+        if (pick >= 2) {
             const int n_dgrad = tiles * splitk * d.ncls, n_wgrad = rider->tiles * rider->split * p.groups;
-            if (big) conv_bwd_kernel<26><<<n_dgrad + n_wgrad, NTHREADS, 0, st>>>(d, p, tiles, splitk, n_dgrad, rider->tiles, rider->split);
-            else conv_bwd_kernel<18><<<n_dgrad + n_wgrad, NTHREADS, 0, st>>>(d, p, tiles, splitk, n_dgrad, rider->tiles, rider->split);
+#define G2S_BWD(BM_, BN_, K_) \
+    conv_bwd_kernel<BM_, BN_, K_><<<n_dgrad + n_wgrad, NTHREADS, 0, st>>>(d, p, tiles, splitk, n_dgrad, rider->tiles, rider->split)
+            if (pick == 2) { if (big) G2S_BWD(64, 64, 26); else G2S_BWD(64, 64, 18); }
+            else { if (big) G2S_BWD(32, 128, 26); else G2S_BWD(32, 128, 18); }
+#undef G2S_BWD
         } else {
             if (big) {
                 if (pick == 0) modconv_kernel<128, 128, 26><<<grid, NTHREADS, 0, st>>>(d);
@@ -839,11 +847,13 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
     } else if (big) {
         if (pick == 0) modconv_kernel<128, 128, 26><<<grid, NTHREADS, 0, st>>>(d);
         else if (pick == 1) modconv_kernel<128, 64, 26><<<grid, NTHREADS, 0, st>>>(d);
-        else modconv_kernel<64, 64, 26><<<grid, NTHREADS, 0, st>>>(d);
+        else if (pick == 2) modconv_kernel<64, 64, 26><<<grid, NTHREADS, 0, st>>>(d);
+        else modconv_kernel<32, 128, 26><<<grid, NTHREADS, 0, st>>>(d);
     } else {
         if (pick == 0) modconv_kernel<128, 128, 18><<<grid, NTHREADS, 0, st>>>(d);
         else if (pick == 1) modconv_kernel<128, 64, 18><<<grid, NTHREADS, 0, st>>>(d);
-        else modconv_kernel<64, 64, 18><<<grid, NTHREADS, 0, st>>>(d);
+        else if (pick == 2) modconv_kernel<64, 64, 18><<<grid, NTHREADS, 0, st>>>(d);
+        else modconv_kernel<32, 128, 18><<<grid, NTHREADS, 0, st>>>(d);
     }
     int rc = check_launch("g2s_modconv");
     if (rc != G2S_OK || !deferred_epilogue) return rc;
