@@ -397,7 +397,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_rider_kernel(WgradParams 
 }
 
 // Backward of one layer of the trained nets in ONE grid: workgroups [0, n_dgrad) run the
-// data-gradient (the convolution kernel, 64x64 or 32x128 tiles), the rest the weight-gradient GEMM
+// data-gradient (the convolution kernel, 64x64 / 32x128 / 64x128 tiles), the rest the weight-gradient GEMM
 // (conv_wgrad_core.h).  Both are latency-bound at these sizes (10-25 us each for a few hundred
 // workgroups): dealt to the CUs together, the layer costs the longer of the two, and one graph node.
 // The flattened workgroup order equals that of the two stand-alone launches, so the XCD-aware tile
@@ -652,8 +652,8 @@ static const TunedConv2d kTuned2d[] = {
 static thread_local int g_force_tile = -1, g_force_splitk = -1;
 
 extern "C" int g2s_modconv_tune(int tile, int splitk) {
-    G2S_REQUIRE(tile >= -2 && tile <= 3 && splitk >= -1 && splitk <= 64 && splitk != 0,
-                "tile must be -1 (built-in), -2 (heuristic without the tuned table) or 0..3, "
+    G2S_REQUIRE(tile >= -2 && tile <= 4 && splitk >= -1 && splitk <= 64 && splitk != 0,
+                "tile must be -1 (built-in), -2 (heuristic without the tuned table) or 0..4, "
                 "splitk -1 (built-in) or 1..64");
     g_force_tile = tile;
     g_force_splitk = splitk;
@@ -774,7 +774,7 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
     G2S_REQUIRE(nmax < (1l << 30) && (long)B * d.Cx * H * W < (1l << 29) && (long)groups * M * Cr * KK < (1l << 29),
                 "problem too large for 32-bit byte offsets");
     hipStream_t st = as_stream(stream);
-    const int cfgs[4][2] = {{128, 128}, {128, 64}, {64, 64}, {32, 128}};
+    const int cfgs[5][2] = {{128, 128}, {128, 64}, {64, 64}, {32, 128}, {64, 128}};
     int pick = 2;
     for (int i = 0; i < 3; i++) {
         const long blocks = (long)groups * cdiv(d.M, cfgs[i][0]) * cdiv(nmax, cfgs[i][1]) * d.ncls;
@@ -832,7 +832,8 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
 #define G2S_BWD(BM_, BN_, K_) \
     conv_bwd_kernel<BM_, BN_, K_><<<n_dgrad + n_wgrad, NTHREADS, 0, st>>>(d, p, tiles, splitk, n_dgrad, rider->tiles, rider->split)
             if (pick == 2) { if (big) G2S_BWD(64, 64, 26); else G2S_BWD(64, 64, 18); }
-            else { if (big) G2S_BWD(32, 128, 26); else G2S_BWD(32, 128, 18); }
+            else if (pick == 3) { if (big) G2S_BWD(32, 128, 26); else G2S_BWD(32, 128, 18); }
+            else { if (big) G2S_BWD(64, 128, 26); else G2S_BWD(64, 128, 18); }
 #undef G2S_BWD
         } else {
             if (big) {
@@ -848,12 +849,14 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
         if (pick == 0) modconv_kernel<128, 128, 26><<<grid, NTHREADS, 0, st>>>(d);
         else if (pick == 1) modconv_kernel<128, 64, 26><<<grid, NTHREADS, 0, st>>>(d);
         else if (pick == 2) modconv_kernel<64, 64, 26><<<grid, NTHREADS, 0, st>>>(d);
-        else modconv_kernel<32, 128, 26><<<grid, NTHREADS, 0, st>>>(d);
+        else if (pick == 3) modconv_kernel<32, 128, 26><<<grid, NTHREADS, 0, st>>>(d);
+        else modconv_kernel<64, 128, 26><<<grid, NTHREADS, 0, st>>>(d);
     } else {
         if (pick == 0) modconv_kernel<128, 128, 18><<<grid, NTHREADS, 0, st>>>(d);
         else if (pick == 1) modconv_kernel<128, 64, 18><<<grid, NTHREADS, 0, st>>>(d);
         else if (pick == 2) modconv_kernel<64, 64, 18><<<grid, NTHREADS, 0, st>>>(d);
-        else modconv_kernel<32, 128, 18><<<grid, NTHREADS, 0, st>>>(d);
+        else if (pick == 3) modconv_kernel<32, 128, 18><<<grid, NTHREADS, 0, st>>>(d);
+        else modconv_kernel<64, 128, 18><<<grid, NTHREADS, 0, st>>>(d);
     }
     int rc = check_launch("g2s_modconv");
     if (rc != G2S_OK || !deferred_epilogue) return rc;

@@ -254,7 +254,7 @@ int g2s_conv3x3_wino(const float *x, const float *U, const float *in_scale, cons
                      float alpha, float gain, int splitk, g2s_stream_t stream);
 
 /* Tuning hook (tools/tune_modconv.py): force the tile configuration (0: 128x128, 1: 128x64,
- * 2: 64x64, 3: 32x128 output channels x pixels) and/or the split-K factor of the calling thread's following
+ * 2: 64x64, 3: 32x128, 4: 64x128 output channels x pixels) and/or the split-K factor of the calling thread's following
  * g2s_modconv / g2s_conv_bias_act / g2s_conv2d launches (slices of the deepest polyphase class of a
  * strided scatter; shallower classes get proportionally fewer); -1 restores the built-in choice
  * (measured tables csrc/modconv_tuned.inc / conv2d_tuned.inc, else a heuristic), tile = -2 selects

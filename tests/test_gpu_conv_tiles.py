@@ -1,4 +1,4 @@
-"""-m gpu: every tile instance of g2s::modconv_kernel (128x128, 128x64, 64x64, 32x128) and its split-K
+"""-m gpu: every tile instance of g2s::modconv_kernel (128x128, 128x64, 64x64, 32x128, 64x128) and its split-K
 paths on the north-star workload's OWN call signatures, value by value against the C oracle.
 
 The heuristic picks the 128-wide tiles only for M > 64 with >= 512 workgroups and the measured
@@ -6,7 +6,7 @@ table (csrc/modconv_tuned.inc) only for B = 8 / 9 signatures, so small shapes ne
 modconv_kernel<128,128,18> / <128,64,18> — the instances that carry a third of the benchmarked
 iteration (profiles/r01_c_bench_timed_region.txt).  Here each signature runs with
     * the built-in choice (tuned table / heuristic),
-    * every tile in {0: 128x128, 1: 128x64, 2: 64x64, 3: 32x128} x split-K in {1, 4, 7} forced through
+    * every tile in {0: 128x128, 1: 128x64, 2: 64x64, 3: 32x128, 4: 64x128} x split-K in {1, 4, 7} forced through
       g2s_modconv_tune,
 forward (in-scale = style, out-scale = demodulation) and transposed (data-gradient: in-scale =
 demodulation), against oracle.capi.modconv (stylegan2-pytorch/model.py:250-291 restated in C,
@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 
 from conv_cases import DOWN2, PLAIN, UP2, expected_modconv  # noqa: E402
 
-TILES = (0, 1, 2, 3)
+TILES = (0, 1, 2, 3, 4)
 SPLITS = (1, 4, 7)
 
 
@@ -147,7 +147,7 @@ def test_forced_tile_is_honoured_and_restored(L):
     """g2s_modconv_tune rejects bad arguments and (-1, -1) restores the built-in choice: same bits
     as before the override for a signature whose built-in choice has no split-K."""
     from gan2shape_amd.modconv import modconv_raw
-    assert L.g2s_modconv_tune(4, 1) != 0 and L.g2s_modconv_tune(0, 0) != 0
+    assert L.g2s_modconv_tune(5, 1) != 0 and L.g2s_modconv_tune(0, 0) != 0
     torch.manual_seed(0)
     x = torch.randn(8, 128, 64, 64, device="cuda")
     w = torch.randn(128, 128, 3, 3, device="cuda") / 34

@@ -447,7 +447,7 @@ def test_fused_backward_launch_equals_the_two_launches(g2s, B, groups, cin, cout
         gx_ref = _conv2d_raw(gy, w, None, cout, cin, k, stride, pad, not transposed, transposed, (H, H), False, 0.0,
                              groups=groups)
         gw_ref = _wgrad(x, gy, k, stride, pad, None, groups) if transposed else _wgrad(gy, x, k, stride, pad, None, groups)
-        for tile, sk in [(-1, -1), (2, 1), (2, 3), (3, 1), (3, 2), (1, 1), (0, 2)]:
+        for tile, sk in [(-1, -1), (2, 1), (2, 3), (3, 1), (3, 2), (4, 1), (4, 3), (1, 1), (0, 2)]:
             L.g2s_modconv_tune(tile, sk)
             gx, gw = _conv_bwd_raw(gy, w, x, cin, cout, k, stride, pad, transposed, None, None, groups)
             assert gx.shape == x.shape and gw.shape == w.shape

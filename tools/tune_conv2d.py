@@ -81,7 +81,7 @@ def main():
             L.g2s_modconv_tune(-2, -1)
             t0 = min(timeit(f), timeit(f))
             res = []
-            for tile in (2, 3, 1, 0):
+            for tile in (2, 3, 4, 1, 0):
                 for sk in SPLITS:
                     L.g2s_modconv_tune(tile, sk)
                     res.append((timeit(f, 10), tile, sk))
