@@ -347,6 +347,17 @@ def roofline_other(device):
     add("g2s fused_bias_act forward (8,128,128,128)", 2 * a.numel() * 4, lambda: fused.fused_bias_act(a, bias, e, 3, 0, 0.2, 2 ** 0.5))
     y = fused.fused_bias_act(a, bias, e, 3, 0, 0.2, 2 ** 0.5)
     add("g2s fused_bias_act backward (8,128,128,128)", 3 * a.numel() * 4, lambda: fused.fused_bias_act(a, e, y, 3, 1, 0.2, 2 ** 0.5))
+    # Adam over the step-3 parameter set (lighting + viewpoint + depth + albedo nets: 22.6 M parameters in
+    # one launch): read p, g, m, v, write p, m, v = 28 bytes per parameter
+    from gan2shape_amd import networks
+    from gan2shape_amd.optim import Adam
+    nets = [networks.LightingNet(128), networks.ViewpointNet(128), networks.DepthNet(128), networks.AlbedoNet(128)]
+    params = [p for n in nets for p in n.to(device).parameters()]
+    for p in params:
+        p.grad = torch.randn_like(p) * 1e-3
+    opt = Adam(params, lr=1e-4, weight_decay=5e-4)
+    add("g2s adam step (step-3 parameter set, %.1f M parameters)" % (sum(p.numel() for p in params) / 1e6),
+        28 * sum(p.numel() for p in params), opt.step)
     return out
 
 

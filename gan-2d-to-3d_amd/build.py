@@ -31,6 +31,7 @@ SOURCES = {
     "geometry.hip": ["-ffp-contract=off"],
     "groupnorm.hip": [],
     "conv_wgrad.hip": [],
+    "adam.hip": [],
 }
 # The kernels take their descriptor struct by value.  Clang copies such a parameter into a private
 # alloca and relies on InstCombine to fold the copy back onto the (constant) kernarg segment — a

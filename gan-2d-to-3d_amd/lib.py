@@ -38,6 +38,8 @@ SIGNATURES = {
     "g2s_conv2d_grouped": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_i, _f, _f, _i, _i, _p]),
     "g2s_conv2d_wgrad_grouped": (_i, [_p, _p, _p] + [_i] * 10 + [_i, _i, _p]),
     "g2s_conv2d_bwd": (_i, [_p, _p, _p] + [_i] * 13 + [_p, _p, _p] + [_i] * 8 + [_p]),
+    "g2s_adam_chunk": (_i64, []),
+    "g2s_adam_step": (_i, [_p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _p]),
     "g2s_rows_dot_scale": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "g2s_demod_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
     "g2s_demod_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),

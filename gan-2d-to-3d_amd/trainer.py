@@ -164,11 +164,12 @@ class Trainer():
         param_list = []
         for model in model_list:
             param_list += [p for p in model.parameters() if p.requires_grad]
-        # GPU: the multi-tensor fused implementation (one or two launches per step instead of ~8
-        # foreach passes over every parameter); same update rule (trainer.py:163-171)
-        fused = bool(param_list) and all(p.is_cuda for p in param_list)
-        return torch.optim.Adam(param_list, lr=lr, betas=betas, weight_decay=weight_decay,
-                                capturable=capturable, fused=fused)
+        # GPU: the whole step as one launch of libg2s (optim.Adam on g2s_adam_step: same update rule,
+        # trainer.py:163-171; device-side step counter, so it can be recorded in HIP graphs)
+        if param_list and all(p.is_cuda for p in param_list):
+            from gan2shape_amd.optim import Adam
+            return Adam(param_list, lr=lr, betas=betas, weight_decay=weight_decay)
+        return torch.optim.Adam(param_list, lr=lr, betas=betas, weight_decay=weight_decay, capturable=capturable)
 
 
 class GeneralizingTrainer2(Trainer):

@@ -219,6 +219,32 @@ int g2s_conv2d_bwd(const float *gy, const float *w, float *gx, int B, int Cr, in
                    const float *A, const float *G, float *dw, int Ca, int Cg, int PH, int PW, int GH, int GW,
                    int dw_is_zero, int groups, g2s_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Adam step of a list of parameter tensors in ONE launch (torch.optim.Adam(params, lr, betas,
+ * weight_decay) of GAN2Shape/trainer.py:163-171: classic L2 weight decay, amsgrad off):
+ *   g' = g + wd p;  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2;  t = *step + 1;
+ *   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps);  then *step = t.
+ * tensors  DEVICE array [n_tensors] of {p, m, v, n, step, ticket} — everything that persists from
+ *          step to step: p, m, v f32 with n elements each; step a DEVICE f32 scalar per tensor
+ *          (steps taken so far, as torch counts them per parameter; advanced by the launch, so a
+ *          captured graph replays the right bias correction); ticket a DEVICE int per tensor, zero
+ *          before and after every launch;
+ * chunk0   DEVICE array [n_tensors + 1]: prefix sums of ceil(n / g2s_adam_chunk()) — tensor i owns
+ *          the chunks chunk0[i] .. chunk0[i + 1] - 1; n_chunks = chunk0[n_tensors];
+ * grads    HOST array [n_tensors] of device pointers to the gradients (they move from step to step;
+ *          passed to the kernel by value).  n_tensors <= G2S_ADAM_MAX_TENSORS per call. */
+#define G2S_ADAM_MAX_TENSORS 128
+typedef struct g2s_adam_tensor {
+    float *p, *m, *v;
+    int64_t n;
+    float *step;
+    int *ticket;
+} g2s_adam_tensor;
+int64_t g2s_adam_chunk(void);
+int g2s_adam_step(const g2s_adam_tensor *tensors, const int *chunk0, const float *const *grads, int n_tensors,
+                  int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  g2s_stream_t stream);
+
 /* fp16-OPERAND form of g2s_modconv / g2s_conv_bias_act (BASELINE config 5, "fp16 MFMA path"): same
  * arguments and geometry; x, w, y stay fp32 in memory, both GEMM operands are rounded to fp16 on
  * their way into LDS and multiplied by v_mfma_f32_32x32x8_f16 with fp32 accumulation.  bias (NULL ok)

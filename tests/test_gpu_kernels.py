@@ -593,3 +593,30 @@ def test_paired_nets_equal_the_two_nets(g2s, names, B):
                 continue
             err = float((p.grad - q.grad).norm())
             assert err <= 2e-3 * float(q.grad.norm()) + 1e-7, (n, err, float(q.grad.norm()))
+
+
+@pytest.mark.gpu
+def test_one_launch_adam_equals_torch_adam(g2s):
+    """optim.Adam (g2s_adam_step: every tensor of the optimiser in one grid, device-side step counter)
+    against torch.optim.Adam — the reference's optimiser, GAN2Shape/trainer.py:163-171 — over 6 steps
+    with fresh gradients: ragged sizes (vector tail, chunk borders), a parameter without a gradient."""
+    from gan2shape_amd.optim import Adam
+    torch.manual_seed(3)
+    shapes = [(64, 32, 4, 4), (1,), (7,), (3, 5, 5, 5), (16385,), (256, 257), (4,), (2, 3)]
+    ref_p = [torch.randn(s, dtype=torch.float64) for s in shapes]
+    ours = [p.float().cuda().requires_grad_(True) for p in ref_p]
+    ref = [p.clone().requires_grad_(True) for p in ref_p]
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), weight_decay=5e-4)
+    o_ours, o_ref = Adam(ours, **kw), torch.optim.Adam(ref, **kw)
+    for it in range(6):
+        for i, (a, b) in enumerate(zip(ours, ref)):
+            if i == 4 and it % 2:       # no gradient this step: torch skips the tensor, so do we
+                a.grad = b.grad = None
+                continue
+            g = torch.randn(b.shape, dtype=torch.float64) * (1 + it)
+            b.grad = g.clone()
+            a.grad = g.float().cuda()
+        o_ours.step()
+        o_ref.step()
+    for a, b in zip(ours, ref):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-5, atol=2e-6)
