@@ -106,7 +106,7 @@ def wino_choice(x, w, mode, transpose, fused):
     # workgroups (>= 2 rounds of whole tiles, or stream-K runs of >= 32 K tiles)
     tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
     blocks = -(-tiles // 64) * -(-M // 64)
-    if tiles < WINO_MIN_TILES or blocks * -(-Cr // 4) < 256 * 32:
+    if tiles < WINO_MIN_TILES or blocks * -(-Cr // 4) < 256 * 32 or M <= 32:   # M <= 32: the direct 32x128 tile
         return None
     return 0
 
