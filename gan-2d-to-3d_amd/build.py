@@ -55,20 +55,27 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "g2s.h"))
-    objs = []
-    relink = force
+    objs, jobs = [], []
     for name, extra in SOURCES.items():
         src = os.path.join(CSRC, name)
         if not os.path.exists(src):
             continue
         obj = os.path.join(LIBDIR, name.replace(".hip", ".o"))
         if force or _newer(src, obj, headers):
-            cmd = [hipcc] + COMMON + extra + ["-c", src, "-o", obj]
+            jobs.append([hipcc] + COMMON + extra + ["-c", src, "-o", obj])
+        objs.append(obj)
+    relink = force or bool(jobs)
+    if jobs:
+        # the translation units are independent: compile them side by side (the two MFMA convolution
+        # kernels take minutes each, the rest seconds)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-            relink = True
-        objs.append(obj)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as pool:
+            list(pool.map(run, jobs))
     if relink or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
