@@ -25,6 +25,7 @@ SOURCES = {
     "modconv.hip": [],
     # packed f32 VALU (v_pk_*) beside MFMAs costs more than it saves (MI355X_MICROARCH.md): no SLP packing
     "winograd.hip": ["-fno-slp-vectorize"],
+    "split_reduce.hip": [],
     "rowops.hip": [],
     "lpips.hip": [],
     "losses.hip": [],

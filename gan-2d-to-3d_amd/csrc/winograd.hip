@@ -37,6 +37,7 @@
 //     workgroups, a run may cross tile borders; partial sums meet by float atomics in a cleared y).
 #include <algorithm>
 #include "g2s_common.h"
+#include "split_reduce.h"
 #include "xcd_tile.h"
 
 namespace g2s {
@@ -62,6 +63,8 @@ struct WinoDesc {
     int units;           // stream-K: tiles * ktiles
     int act;
     float act_alpha, act_gain;
+    float *part;         // split-K with a workspace: slice s stores to part[s * part_n + offset in y]
+    long part_n;
 };
 
 // PARTIAL: Cr is not a multiple of the K tile (the last tile's surplus channels read as zero).
@@ -367,6 +370,17 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
             if (vec) {
                 *reinterpret_cast<float2 *>(dst) = float2{y[0], y[1]};
                 if (row1) *reinterpret_cast<float2 *>(dst + d.W) = float2{y[2], y[3]};
+            } else if (split && d.part) {
+                float *pd = d.part + (size_t)blockIdx.y * d.part_n + (dst - d.y);
+                if (col1 && (d.W & 1) == 0) {
+                    *reinterpret_cast<float2 *>(pd) = float2{y[0], y[1]};
+                    if (row1) *reinterpret_cast<float2 *>(pd + d.W) = float2{y[2], y[3]};
+                } else {
+                    pd[0] = y[0];
+                    if (col1) pd[1] = y[1];
+                    if (row1) pd[d.W] = y[2];
+                    if (row1 && col1) pd[d.W + 1] = y[3];
+                }
             } else if (split) {
                 unsafeAtomicAdd(dst, y[0]);
                 if (col1) unsafeAtomicAdd(dst + 1, y[1]);
@@ -438,7 +452,8 @@ extern "C" int g2s_wino_weights(const float *w, float *U, int Cout, int Cin, int
 
 extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_scale, const float *out_scale,
                                 const float *bias, float *y, int B, int Cr, int M, int H, int W, int act,
-                                float alpha, float gain, int splitk, g2s_stream_t stream) {
+                                float alpha, float gain, int splitk, float *ws, int64_t ws_floats,
+                                g2s_stream_t stream) {
     G2S_REQUIRE(x && U && y, "x, U, y must not be NULL");
     G2S_REQUIRE(B > 0 && Cr > 0 && M > 0 && H >= 2 && W >= 2, "sizes must be positive (H, W >= 2)");
     G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
@@ -473,9 +488,19 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
     d.upw = 0;
     d.units = tiles * d.ktiles;
     bool partial_sums;
+    const size_t y_floats = (size_t)B * M * H * W;
+    bool use_part = false;
     if (splitk > 0) {
         splitk = std::min(splitk, d.ktiles);
+        splitk = cdiv(d.ktiles, cdiv(d.ktiles, splitk));   // no empty slices
         partial_sums = splitk > 1;
+        // with a workspace the slices store their partial sums side by side and a reduce pass finishes
+        // the launch (split_reduce.h): no clear of y, no atomic burst, no separate epilogue launch
+        use_part = partial_sums && ws && splitk <= SPLIT_REDUCE_MAX && (size_t)splitk * y_floats <= (size_t)ws_floats;
+        if (use_part) {
+            d.part = ws;
+            d.part_n = (long)y_floats;
+        }
     } else if (splitk < 0) {   // stream-K over -splitk workgroups (tests)
         d.upw = cdiv(d.units, std::min(-splitk, d.units));
         grid_x = cdiv(d.units, d.upw);
@@ -499,7 +524,7 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
     }
     d.splitk = splitk;
     hipStream_t st = as_stream(stream);
-    if (partial_sums && hipMemsetAsync(y, 0, (size_t)B * M * H * W * sizeof(float), st) != hipSuccess)
+    if (partial_sums && !use_part && hipMemsetAsync(y, 0, y_floats * sizeof(float), st) != hipSuccess)
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
     dim3 grid(grid_x, splitk, 1);
     const bool partial = Cr % WKC != 0;
@@ -515,6 +540,8 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
     }
 #undef G2S_WINO_LAUNCH
     int rc = check_launch("g2s_conv3x3_wino");
+    if (rc == G2S_OK && use_part)
+        return split_reduce_launch(ws, splitk, (int64_t)y_floats, y, bias, (int64_t)H * W, M, act, alpha, gain, stream);
     if (rc != G2S_OK || !deferred) return rc;
     return g2s_fused_bias_act(y, bias, nullptr, y, (int64_t)B * M * H * W, (int64_t)H * W, M, act ? 3 : 1, 0,
                               alpha, act ? gain : 1.0f, G2S_F32, stream);

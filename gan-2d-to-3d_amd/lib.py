@@ -32,7 +32,7 @@ SIGNATURES = {
     "g2s_modconv_tune": (_i, [_i, _i]),
     "g2s_wino_weights_floats": (_sz, [_i, _i]),
     "g2s_wino_weights": (_i, [_p, _p, _i, _i, _i, _p]),
-    "g2s_conv3x3_wino": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "g2s_conv3x3_wino": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p, _i64, _p]),
     "g2s_conv2d": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_i, _f, _f, _i, _p]),
     "g2s_conv2d_wgrad": (_i, [_p, _p, _p] + [_i] * 10 + [_i, _p]),
     "g2s_conv2d_grouped": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_i, _f, _f, _i, _i, _p]),
@@ -98,6 +98,24 @@ def ptr(t):
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# Scratch of the split-K Winograd launches (include/g2s.h, `ws`): one buffer per (device, stream) —
+# launches on one stream are ordered, so they can share it.  64 MB hold 8 slices of the largest output
+# such a launch writes in the workload (9 x 512 x 16 x 16 floats).
+SPLIT_WS_FLOATS = 16 * 1024 * 1024
+_split_ws = {}
+
+
+def split_ws():
+    """(pointer, floats) of the current stream's split workspace, allocated on first use."""
+    st = torch.cuda.current_stream()
+    key = (st.device_index, st.cuda_stream)
+    t = _split_ws.get(key)
+    if t is None:
+        t = _split_ws[key] = torch.empty(SPLIT_WS_FLOATS, dtype=torch.float32,
+                                         device=torch.device("cuda", st.device_index))
+    return C.c_void_p(t.data_ptr()), t.numel()
 
 
 def require_cuda(*tensors):

@@ -142,7 +142,7 @@ def _wino_launch(x, w, in_scale, out_scale, bias, transpose, act, alpha, gain, y
                   2.0 * 16 * tiles * M * Cr):
         _lib.check(L.g2s_conv3x3_wino(_lib.ptr(x), _lib.ptr(U), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                       _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W, int(act), float(alpha),
-                                      float(gain), int(splitk), _lib.stream()))
+                                      float(gain), int(splitk), *_lib.split_ws(), _lib.stream()))
     return y
 
 

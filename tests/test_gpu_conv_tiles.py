@@ -129,7 +129,7 @@ def test_conv_bias_act_every_tile_vs_oracle(L, B, cin, cout, H, alpha, gain):
     try:
         _check(conv_bias_act(xd, wd, bd, PLAIN, alpha, gain), exp, cin * 9, "built-in choice (measured table)")
         from gan2shape_amd import modconv as mc
-        for force in (0, 1, -256):      # Winograd with the fused / deferred epilogue: library choice, whole tiles, stream-K
+        for force in (0, 1, 4, -256):   # Winograd with the fused / reduce-pass / deferred epilogue: library choice, whole tiles, split-K, stream-K
             mc.WINO_FORCE = force
             try:
                 _check(conv_bias_act(xd, wd, bd, PLAIN, alpha, gain), exp, cin * 9, f"winograd partition {force}")
@@ -201,6 +201,19 @@ def test_winograd_vs_oracle(L, B, cin, cout, H, W, transpose):
             _check(mc.modconv_raw(xd, wd, sid, sod, PLAIN, transpose), exp, cx * 9, f"winograd partition {sk}")
         mc.WINO_FORCE = 0
         _check(mc.modconv_raw(xd, wd, None, None, PLAIN, transpose), exp_plain, cx * 9, "winograd, no scales")
+        # split-K without a workspace (a caller that passes ws = NULL): cleared y + float atomics
+        # instead of stored slices + reduce pass
+        from gan2shape_amd import lib
+        real = lib.split_ws
+        lib.split_ws = lambda: (None, 0)
+        try:
+            for sk in (3, 8):
+                mc.WINO_FORCE = sk
+                _check(mc.modconv_raw(xd, wd, sid, sod, PLAIN, transpose), exp, cx * 9, f"split-K {sk}, atomics")
+        finally:
+            lib.split_ws = real
+        mc.WINO_FORCE = 8
+        _check(mc.modconv_raw(xd, wd, sid, sod, PLAIN, transpose), exp, cx * 9, "split-K 8, stored slices")
     finally:
         mc.WINOGRAD, mc.WINO_FORCE = saved
 

@@ -45,7 +45,7 @@ wrap("g2s_modconv", lambda a: (a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12]
 # g2s_conv_bias_act(x,w,bias,y,B,Cin,Cout,H,W,k,mode,act,alpha,gain,stream)
 wrap("g2s_conv_bias_act", lambda a: (a[4], a[5], a[6], a[7], a[8], a[9], a[10], 0, False, False))
 
-# g2s_conv3x3_wino(x,U,in_scale,out_scale,bias,y,B,Cr,M,H,W,act,alpha,gain,splitk,stream)
+# g2s_conv3x3_wino(x,U,in_scale,out_scale,bias,y,B,Cr,M,H,W,act,alpha,gain,splitk,ws,ws_floats,stream)
 wrap("g2s_conv3x3_wino", lambda a: (a[6], a[7], a[8], a[9], a[10], 3, 0, 0, a[2] is not None, a[3] is not None))
 
 for kind in [int(x) for x in sys.argv[1:]] or [1, 2, 3]:
