@@ -86,8 +86,8 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
     // every CU gets the same amount of matrix work whatever the tile count (one workgroup per CU
     // fits: a launch of 1.1 rounds of equal tiles would otherwise take 2).
     int unit, unit_end;
+    const int g = xcd_logical_tile();   // stream-K: index of this workgroup's run
     {
-        const int g = xcd_logical_tile();
         if (d.upw) {
             unit = g * d.upw;
             unit_end = min(d.units, unit + d.upw);
@@ -359,11 +359,15 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
             }
             float y[4] = {s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
             const float sc = ob ? ob[m] : 1.0f;
-            const float bi = d.bias ? d.bias[m] : 0.0f;
+            // a partial sum that goes to a workspace slot carries the (linear) output scale only: the
+            // reduce pass adds bias and activation; whole tiles and the atomic path finish here (for
+            // the atomic path the host has cleared bias / activation: they run as a deferred launch)
+            const bool raw = split && d.part != nullptr;
+            const float bi = (d.bias && !raw) ? d.bias[m] : 0.0f;
     #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float v = y[q] * sc + bi;
-                if (d.act) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
+                if (d.act && !raw) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
                 y[q] = v;
             }
             float *dst = yb + (size_t)m * HW;
@@ -371,7 +375,9 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
                 *reinterpret_cast<float2 *>(dst) = float2{y[0], y[1]};
                 if (row1) *reinterpret_cast<float2 *>(dst + d.W) = float2{y[2], y[3]};
             } else if (split && d.part) {
-                float *pd = d.part + (size_t)blockIdx.y * d.part_n + (dst - d.y);
+                // slot: the split-K slice, or the position of this run among the runs that share the tile
+                const int slot = d.upw ? g - (tile_id * d.ktiles) / d.upw : (int)blockIdx.y;
+                float *pd = d.part + (size_t)slot * d.part_n + (dst - d.y);
                 if (col1 && (d.W & 1) == 0) {
                     *reinterpret_cast<float2 *>(pd) = float2{y[0], y[1]};
                     if (row1) *reinterpret_cast<float2 *>(pd + d.W) = float2{y[2], y[3]};
@@ -393,6 +399,42 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
                 if (row1 && col1) dst[d.W + 1] = y[3];
             }
         }
+    }
+}
+
+// Second pass of a stream-K launch with a workspace: every output pair (2 pixels of one 2x2 tile)
+// finds its tile, the number of runs that shared it, adds their slots, applies bias + activation.
+// Tiles that one run computed whole were finished by the convolution kernel and are left alone.
+__global__ __launch_bounds__(256) void wino_streamk_reduce_kernel(WinoDesc d) {
+    const int W2 = d.W >> 1;                       // W is even on this path
+    const long pairs = (long)d.B * d.M * d.H * W2;
+    const int tiles_m = (d.M + WBM - 1) / WBM, per_img = d.TH * d.TW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % W2);
+        long r = i / W2;
+        const int oy = (int)(r % d.H);
+        r /= d.H;
+        const int m = (int)(r % d.M), b = (int)(r / d.M);
+        const int n = b * per_img + (oy >> 1) * d.TW + px;
+        const int tile_id = (n / WBT) * tiles_m + m / WBM;
+        const int u0 = tile_id * d.ktiles;
+        const int parts = (u0 + d.ktiles - 1) / d.upw - u0 / d.upw + 1;
+        if (parts == 1) continue;
+        const size_t o = (((size_t)b * d.M + m) * d.H + oy) * d.W + 2 * px;
+        float2 acc{0.f, 0.f};
+        for (int s = 0; s < parts; s++) {
+            const float2 v = *reinterpret_cast<const float2 *>(d.part + (size_t)s * d.part_n + o);
+            acc.x += v.x;
+            acc.y += v.y;
+        }
+        const float bi = d.bias ? d.bias[m] : 0.0f;
+        acc.x += bi;
+        acc.y += bi;
+        if (d.act) {
+            acc.x = (acc.x > 0.0f ? acc.x : acc.x * d.act_alpha) * d.act_gain;
+            acc.y = (acc.y > 0.0f ? acc.y : acc.y * d.act_alpha) * d.act_gain;
+        }
+        *reinterpret_cast<float2 *>(d.y + o) = acc;
     }
 }
 
@@ -517,7 +559,18 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
         }
         partial_sums = d.upw != 0;
     }
-    const bool deferred = partial_sums && (bias != nullptr || act != 0);
+    // stream-K with a workspace: every run stores its share of a split tile to a slot of its own
+    // (at most ceil(ktiles / upw) + 1 runs meet in a tile) and wino_streamk_reduce_kernel finishes them
+    bool streamk_part = false;
+    if (d.upw && ws && W % 2 == 0) {
+        const int slots = cdiv(d.ktiles, d.upw) + 1;
+        if (slots <= SPLIT_REDUCE_MAX && (size_t)slots * y_floats <= (size_t)ws_floats) {
+            streamk_part = use_part = true;
+            d.part = ws;
+            d.part_n = (long)y_floats;
+        }
+    }
+    const bool deferred = partial_sums && !streamk_part && (bias != nullptr || act != 0);
     if (deferred) {
         d.bias = nullptr;
         d.act = 0;
@@ -540,6 +593,11 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
     }
 #undef G2S_WINO_LAUNCH
     int rc = check_launch("g2s_conv3x3_wino");
+    if (rc == G2S_OK && streamk_part) {
+        const long pairs = (long)y_floats / 2;
+        wino_streamk_reduce_kernel<<<(unsigned)std::min<long>((pairs + 255) / 256, 256 * 8), 256, 0, st>>>(d);
+        return check_launch("g2s_conv3x3_wino (stream-K reduce)");
+    }
     if (rc == G2S_OK && use_part)
         return split_reduce_launch(ws, splitk, (int64_t)y_floats, y, bias, (int64_t)H * W, M, act, alpha, gain, stream);
     if (rc != G2S_OK || !deferred) return rc;
