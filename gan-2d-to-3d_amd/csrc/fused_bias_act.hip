@@ -203,3 +203,47 @@ extern "C" int g2s_noise_bias_act(const float *x, const float *noise, const floa
     }
     return check_launch("g2s_noise_bias_act");
 }
+
+// ------------------------------------------------------------------------------------------------
+// y = (a + b + bias[c]) * scale: the residual joins of the frozen nets as one pass — ToRGB
+// (stylegan2-pytorch/model.py:371-377: conv + bias, then + upsample(skip)) and the discriminator's
+// ResBlock (model.py:693-697: (out + skip) / sqrt(2)).  b and bias may be NULL.
+namespace g2s {
+
+__global__ __launch_bounds__(256) void add_bias_scale_kernel(const float *a, const float *b, const float *bias,
+                                                             float *y, int64_t n, int64_t hw, int C, float scale) {
+    const bool vec = (n & 3) == 0 && (hw & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (vec) {
+            float4 v = *reinterpret_cast<const float4 *>(a + i);
+            if (b) {
+                const float4 w = *reinterpret_cast<const float4 *>(b + i);
+                v.x += w.x;
+                v.y += w.y;
+                v.z += w.z;
+                v.w += w.w;
+            }
+            const float bi = bias ? bias[(i / hw) % C] : 0.0f;   // hw % 4 == 0: one channel per lane
+            *reinterpret_cast<float4 *>(y + i) = float4{(v.x + bi) * scale, (v.y + bi) * scale, (v.z + bi) * scale,
+                                                        (v.w + bi) * scale};
+        } else {
+            for (int64_t j = i; j < i + 4 && j < n; j++)
+                y[j] = (a[j] + (b ? b[j] : 0.0f) + (bias ? bias[(j / hw) % C] : 0.0f)) * scale;
+        }
+    }
+}
+
+}  // namespace g2s
+
+extern "C" int g2s_add_bias_scale(const float *a, const float *b, const float *bias, float *y, int64_t n, int64_t hw,
+                                  int C, float scale, g2s_stream_t stream) {
+    G2S_REQUIRE(a && y, "a and y must not be NULL");
+    G2S_REQUIRE(n > 0 && hw > 0 && C > 0, "n, hw, C must be positive");
+    const int64_t quads = (n + 3) / 4;
+    const int blocks = (int)std::min<int64_t>((quads + 255) / 256, 256 * 8);
+    g2s::add_bias_scale_kernel<<<blocks, 256, 0, g2s::as_stream(stream)>>>(a, b, bias, y, n, hw, C, scale);
+    return g2s::check_launch("g2s_add_bias_scale");
+}
+

@@ -106,3 +106,42 @@ def fused_noise_bias_act(x, noise, noise_w, bias, negative_slope=0.2, scale=2 **
     if x.dtype != torch.float32:
         raise RuntimeError("fused_noise_bias_act: float32 only")
     return _NoiseBiasLeakyReLU.apply(x, noise, noise_w, bias, negative_slope, scale)
+
+
+class _AddBiasScale(Function):
+    """(a + b + bias[c]) * scale in one launch (g2s_add_bias_scale); b / bias may be None."""
+
+    @staticmethod
+    def forward(ctx, a, b, bias, scale):
+        _lib.require_cuda(a, b, bias)
+        a = a.contiguous()
+        bc = None if b is None else b.contiguous()
+        bv = None if bias is None else bias.reshape(-1).contiguous()
+        y = torch.empty_like(a)
+        C_, hw = a.shape[1], a.shape[2] * a.shape[3]
+        _lib.check(_lib.load().g2s_add_bias_scale(_lib.ptr(a), _lib.ptr(bc), _lib.ptr(bv), _lib.ptr(y), a.numel(), hw,
+                                                  C_, float(scale), _lib.stream()))
+        ctx.scale = float(scale)
+        ctx.bias_shape = None if bias is None else bias.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = g if ctx.scale == 1.0 else g * ctx.scale
+        gbias = None
+        if ctx.bias_shape is not None and ctx.needs_input_grad[2]:
+            gbias = gs.sum((0, 2, 3)).reshape(ctx.bias_shape)
+        return gs, (gs if ctx.needs_input_grad[1] else None), gbias, None
+
+
+def add_bias_scale(a, b=None, bias=None, scale=1.0):
+    """(a + b + bias) * scale for [B, C, H, W] tensors (bias broadcast over channels, any shape with C
+    elements): ToRGB's `conv + bias + upsample(skip)` (stylegan2-pytorch/model.py:371-377) and the
+    discriminator ResBlock's `(out + skip) / sqrt(2)` (model.py:693-697) as one pass on the GPU."""
+    if a.is_cuda and a.dtype == torch.float32 and a.dim() == 4:
+        return _AddBiasScale.apply(a, b, bias, scale)
+    out = a if b is None else a + b
+    if bias is not None:
+        out = out + bias.reshape(1, -1, 1, 1)
+    return out if scale == 1.0 else out * scale
+

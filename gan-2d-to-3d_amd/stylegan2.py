@@ -23,7 +23,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from .modconv import DOWN2, PLAIN, UP2, conv2d, conv2d_supported, conv_bias_act, demodulation, modconv
-from .op import FusedLeakyReLU, fused_leaky_relu, fused_noise_bias_act, upfirdn2d
+from .op import FusedLeakyReLU, add_bias_scale, fused_leaky_relu, fused_noise_bias_act, upfirdn2d
 
 
 class PixelNorm(nn.Module):
@@ -289,10 +289,8 @@ class ToRGB(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
     def forward(self, input, style, skip=None):
-        out = self.conv(input, style) + self.bias
-        if skip is not None:
-            out = out + self.upsample(skip)
-        return out
+        # conv + bias (+ upsample(skip)) as one pass
+        return add_bias_scale(self.conv(input, style), None if skip is None else self.upsample(skip), self.bias)
 
 
 class _StyleRow:
@@ -549,7 +547,7 @@ class ResBlock(nn.Module):
 
     def forward(self, input):
         out = self.conv2(self.conv1(input))
-        return (out + self.skip(input)) / math.sqrt(2)
+        return add_bias_scale(out, self.skip(input), None, 1 / math.sqrt(2))
 
 
 class Discriminator(nn.Module):

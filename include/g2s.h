@@ -111,6 +111,12 @@ int g2s_fused_bias_act(const void *x, const void *bias, const void *ref, void *y
                        int64_t step_b, int64_t size_b, int act, int grad, float alpha,
                        float scale, int dtype, g2s_stream_t stream);
 
+/* Residual joins of the frozen nets in one pass: y = (a + b + bias[c]) * scale, c = (i / hw) % C.
+ * ToRGB: conv + bias + upsample(skip) (stylegan2-pytorch/model.py:371-377); discriminator ResBlock:
+ * (out + skip) / sqrt(2) (model.py:693-697).  a, b, y [n] f32; b and bias [C] may be NULL. */
+int g2s_add_bias_scale(const float *a, const float *b, const float *bias, float *y, int64_t n, int64_t hw, int C,
+                       float scale, g2s_stream_t stream);
+
 /* StyledConv tail in one pass (stylegan2-pytorch/model.py:349-355: NoiseInjection then
  * FusedLeakyReLU): y = lrelu_alpha(x + noise_w * noise[hw] + bias[c]) * scale.
  * x,y [B, C, HW] f32; noise [HW] f32 (one map broadcast over B and C) or NULL;

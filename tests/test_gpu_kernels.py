@@ -620,3 +620,27 @@ def test_one_launch_adam_equals_torch_adam(g2s):
         o_ref.step()
     for a, b in zip(ours, ref):
         np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8, 3, 64, 64), (2, 5, 7, 9), (3, 128, 16, 16)])
+def test_add_bias_scale_matches_torch(g2s, shape):
+    """(a + b + bias[c]) * scale — ToRGB's conv + bias + upsample(skip) and the ResBlock's
+    (out + skip) / sqrt(2) (stylegan2-pytorch/model.py:371-377, 693-697) as one launch: values and
+    gradients against the torch expressions, with and without b / bias."""
+    from gan2shape_amd.op import add_bias_scale
+    torch.manual_seed(1)
+    for use_b, use_bias, scale in [(True, True, 1.0), (True, False, 2 ** -0.5), (False, True, 1.0)]:
+        a = torch.randn(shape, device="cuda", requires_grad=True)
+        b = torch.randn(shape, device="cuda", requires_grad=True) if use_b else None
+        bias = torch.randn(1, shape[1], 1, 1, device="cuda", requires_grad=True) if use_bias else None
+        y = add_bias_scale(a, b, bias, scale)
+        ref = a if b is None else a + b
+        if bias is not None:
+            ref = ref + bias
+        ref = ref * scale
+        torch.testing.assert_close(y, ref, rtol=1e-6, atol=1e-6)
+        g = torch.randn_like(y)
+        ins = [t for t in (a, b, bias) if t is not None]
+        for got, want in zip(torch.autograd.grad(y, ins, g), torch.autograd.grad(ref, ins, g)):
+            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
