@@ -23,6 +23,7 @@ SOURCES = {
     "fused_bias_act.hip": [],
     "upfirdn2d.hip": [],
     "modconv.hip": [],
+    "thinconv.hip": [],
     # packed f32 VALU (v_pk_*) beside MFMAs costs more than it saves (MI355X_MICROARCH.md): no SLP packing
     "winograd.hip": ["-fno-slp-vectorize"],
     "split_reduce.hip": [],

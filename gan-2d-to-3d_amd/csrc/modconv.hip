@@ -22,6 +22,7 @@
 // Small layers (4x4 .. 16x16) use 64x64 tiles and split-K with float atomics to fill 256 CUs.
 #include "g2s_common.h"
 #include "conv_wgrad_core.h"
+#include "thinconv.h"
 #include "xcd_tile.h"
 
 namespace g2s {
@@ -874,6 +875,11 @@ static int modconv_launch(const float *x, const float *w, const float *in_scale,
     G2S_REQUIRE(k == 1 || k == 3, "kernel size must be 1 or 3 (got %d)", k);
     G2S_REQUIRE(mode == G2S_CONV_PLAIN || mode == G2S_CONV_UP2 || mode == G2S_CONV_DOWN2,
                 "unsupported mode %d", mode);
+    // fromRGB (1x1 from 3 channels over >= 64 K pixels) runs as a streaming kernel (thinconv.hip) instead
+    // of an MFMA tile whose K is padding.  A forced tile keeps the call on the MFMA kernel (tests).
+    if (!f16_operands && !in_scale && !out_scale && mode == G2S_CONV_PLAIN && g_force_tile == -1 &&
+        g_force_splitk == -1 && thin_conv_eligible(B, Cin, Cout, H, W, k, transpose))
+        return thin_conv_launch(x, w, bias, y, B, Cin, Cout, H, W, act, act_alpha, act_gain, stream);
     ConvGeom g{};
     g.k = k;
     g.stride = mode == G2S_CONV_PLAIN ? 1 : 2;

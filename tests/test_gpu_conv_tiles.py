@@ -270,3 +270,25 @@ def test_modconv_f16_operands_vs_oracle(L, B, cin, cout, H, k, mode, transpose):
     rms = float(np.sqrt((exp.astype(np.float64) ** 2).mean()))
     assert np.abs(got - exp).max() <= 4e-3 * rms, (np.abs(got - exp).max(), rms)
     assert np.linalg.norm(got - exp) <= 1e-3 * np.linalg.norm(exp)
+
+
+# ----------------------------------------------------------------------------- fromRGB: the thin 1x1 path
+@pytest.mark.parametrize("B,cin,cout,H,W", [(8, 3, 128, 128, 128), (5, 4, 24, 120, 132), (3, 1, 40, 160, 140)])
+def test_thin_1x1_path_vs_oracle_and_mfma(L, B, cin, cout, H, W):
+    """ConvLayer(3, C, 1) + bias + leaky-ReLU (the discriminator's fromRGB, stylegan2-pytorch/model.py:709)
+    runs as a streaming kernel (csrc/thinconv.hip) when it covers >= 64 K pixels: against the C oracle at
+    the tile tests' tolerance and against the MFMA kernel the same call takes when a tile is forced."""
+    from gan2shape_amd.modconv import conv_bias_act
+    rng = np.random.default_rng(B + cin + cout + H)
+    w = (rng.standard_normal((cout, cin, 1, 1)) / math.sqrt(cin)).astype(np.float32)
+    x = rng.standard_normal((B, cin, H, W)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    pre = expected_modconv(x, w, None, None, PLAIN, 0) + b[None, :, None, None]
+    exp = (np.where(pre > 0, pre, pre * 0.2) * 2 ** 0.5).astype(np.float32)
+    try:
+        L.g2s_modconv_tune(-1, -1)
+        _check(conv_bias_act(dev(x), dev(w), dev(b), PLAIN, 0.2, 2 ** 0.5), exp, cin, "thin path")
+        L.g2s_modconv_tune(2, 1)
+        _check(conv_bias_act(dev(x), dev(w), dev(b), PLAIN, 0.2, 2 ** 0.5), exp, cin, "MFMA path (forced tile)")
+    finally:
+        L.g2s_modconv_tune(-1, -1)
