@@ -29,6 +29,7 @@ SOURCES = {
     "split_reduce.hip": [],
     "rowops.hip": [],
     "lpips.hip": [],
+    "pool.hip": [],
     "losses.hip": [],
     "geometry.hip": ["-ffp-contract=off"],
     "groupnorm.hip": [],

@@ -1,0 +1,105 @@
+// pool.hip — nn.MaxPool2d(kernel_size=2, stride=2) of the VGG16 trunk (lpips/pretrained_networks.py:
+// 97-135 via torchvision's vgg16.features), forward and backward, as two streaming kernels.
+// torch's backward clears the whole input gradient (one fill per pool) and then scatters through
+// saved int64 indices; here the backward re-derives the winner of each 2x2 window from the saved
+// input — first maximum in row-major order, NaN wins, exactly torch's forward rule — and WRITES all
+// four input gradients of the window: no fill, no index tensor, 16-byte accesses.
+// Lane = 4 consecutive output pixels (8 input pixels of two rows).  H, W even, W % 8 == 0.
+#include "g2s_common.h"
+
+namespace g2s {
+
+__device__ __forceinline__ bool beats(float v, float best) { return v > best || v != v; }
+
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float *x, float *y, long quads, int OH, int OW4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % OW4);
+        const long r = i / OW4;                 // (plane, output row)
+        const long plane = r / OH;
+        const int oy = (int)(r - plane * OH);
+        const int W = OW4 * 8;
+        const float4 *top = reinterpret_cast<const float4 *>(x + (plane * 2 * OH + 2 * oy) * W + 8 * q);
+        const float4 *bot = reinterpret_cast<const float4 *>(x + (plane * 2 * OH + 2 * oy + 1) * W + 8 * q);
+        const float4 t0 = top[0], t1 = top[1], b0 = bot[0], b1 = bot[1];
+        auto win = [](float a, float b, float c, float d) {
+            float m = a;
+            if (beats(b, m)) m = b;
+            if (beats(c, m)) m = c;
+            if (beats(d, m)) m = d;
+            return m;
+        };
+        float4 o;
+        o.x = win(t0.x, t0.y, b0.x, b0.y);
+        o.y = win(t0.z, t0.w, b0.z, b0.w);
+        o.z = win(t1.x, t1.y, b1.x, b1.y);
+        o.w = win(t1.z, t1.w, b1.z, b1.w);
+        reinterpret_cast<float4 *>(y)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *x, const float *gy, float *gx, long quads,
+                                                           int OH, int OW4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % OW4);
+        const long r = i / OW4;
+        const long plane = r / OH;
+        const int oy = (int)(r - plane * OH);
+        const int W = OW4 * 8;
+        const long o_top = (plane * 2 * OH + 2 * oy) * W + 8 * q, o_bot = o_top + W;
+        const float4 t0 = *reinterpret_cast<const float4 *>(x + o_top), t1 = *reinterpret_cast<const float4 *>(x + o_top + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(x + o_bot), b1 = *reinterpret_cast<const float4 *>(x + o_bot + 4);
+        const float4 g = reinterpret_cast<const float4 *>(gy)[i];
+        // winner of a window (a b / c d): index of the first maximum in the order a, b, c, d
+        auto route = [](float a, float b, float c, float d, float gv, float &ga, float &gb, float &gc, float &gd) {
+            int k = 0;
+            float m = a;
+            if (beats(b, m)) { m = b; k = 1; }
+            if (beats(c, m)) { m = c; k = 2; }
+            if (beats(d, m)) { m = d; k = 3; }
+            ga = k == 0 ? gv : 0.0f;
+            gb = k == 1 ? gv : 0.0f;
+            gc = k == 2 ? gv : 0.0f;
+            gd = k == 3 ? gv : 0.0f;
+        };
+        float4 gt0, gt1, gb0, gb1;
+        route(t0.x, t0.y, b0.x, b0.y, g.x, gt0.x, gt0.y, gb0.x, gb0.y);
+        route(t0.z, t0.w, b0.z, b0.w, g.y, gt0.z, gt0.w, gb0.z, gb0.w);
+        route(t1.x, t1.y, b1.x, b1.y, g.z, gt1.x, gt1.y, gb1.x, gb1.y);
+        route(t1.z, t1.w, b1.z, b1.w, g.w, gt1.z, gt1.w, gb1.z, gb1.w);
+        *reinterpret_cast<float4 *>(gx + o_top) = gt0;
+        *reinterpret_cast<float4 *>(gx + o_top + 4) = gt1;
+        *reinterpret_cast<float4 *>(gx + o_bot) = gb0;
+        *reinterpret_cast<float4 *>(gx + o_bot + 4) = gb1;
+    }
+}
+
+}  // namespace g2s
+
+using namespace g2s;
+
+static int pool_args(const void *a, const void *b, int64_t planes, int H, int W) {
+    G2S_REQUIRE(a && b, "NULL pointer argument");
+    G2S_REQUIRE(planes > 0 && H >= 2 && W >= 8 && H % 2 == 0 && W % 8 == 0, "H even, W a multiple of 8");
+    G2S_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0, "16-byte alignment");
+    return G2S_OK;
+}
+
+extern "C" int g2s_maxpool2x2_fwd(const float *x, float *y, int64_t planes, int H, int W, g2s_stream_t stream) {
+    const int rc = pool_args(x, y, planes, H, W);
+    if (rc != G2S_OK) return rc;
+    const long quads = planes * (H / 2) * (W / 8);
+    maxpool2_fwd_kernel<<<(unsigned)std::min<long>((quads + 255) / 256, 256 * 8), 256, 0, as_stream(stream)>>>(
+        x, y, quads, H / 2, W / 8);
+    return check_launch("g2s_maxpool2x2_fwd");
+}
+
+extern "C" int g2s_maxpool2x2_bwd(const float *x, const float *gy, float *gx, int64_t planes, int H, int W,
+                                  g2s_stream_t stream) {
+    const int rc = pool_args(x, gx, planes, H, W);
+    if (rc != G2S_OK) return rc;
+    G2S_REQUIRE(gy && (reinterpret_cast<uintptr_t>(gy) & 15) == 0, "gy NULL or misaligned");
+    const long quads = planes * (H / 2) * (W / 8);
+    maxpool2_bwd_kernel<<<(unsigned)std::min<long>((quads + 255) / 256, 256 * 8), 256, 0, as_stream(stream)>>>(
+        x, gy, gx, quads, H / 2, W / 8);
+    return check_launch("g2s_maxpool2x2_bwd");
+}

@@ -24,6 +24,8 @@ SIGNATURES = {
     "g2s_raster_depth_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _f, _i, _p, _p]),
     "g2s_raster_rgb_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _f, _p, _p]),
     "g2s_fused_bias_act": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _f, _f, _i, _p]),
+    "g2s_maxpool2x2_fwd": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "g2s_maxpool2x2_bwd": (_i, [_p, _p, _p, _i64, _i, _i, _p]),
     "g2s_add_bias_scale": (_i, [_p, _p, _p, _p, _i64, _i64, _i, _f, _p]),
     "g2s_noise_bias_act": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p]),
     "g2s_upfirdn2d": (_i, [_p, _p, _p] + [_i] * 14 + [_p]),

@@ -60,6 +60,39 @@ class _LpipsLayer(Function):
         return g0, None, None, gout
 
 
+class _MaxPool2x2(Function):
+    """nn.MaxPool2d(2, 2) on g2s_maxpool2x2_*: the backward routes each output gradient to the first
+    maximum of its window (torch's rule) straight from the saved input — no cleared gradient buffer,
+    no index tensor."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C_, H, W = x.shape
+        y = torch.empty((B, C_, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().g2s_maxpool2x2_fwd(_lib.ptr(x), _lib.ptr(y), B * C_, H, W, _lib.stream()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        B, C_, H, W = x.shape
+        gx = torch.empty_like(x)
+        _lib.check(_lib.load().g2s_maxpool2x2_bwd(_lib.ptr(x), _lib.ptr(gy.contiguous()), _lib.ptr(gx), B * C_, H, W,
+                                                  _lib.stream()))
+        return gx
+
+
+def max_pool_2x2(mod, x):
+    """`mod(x)` for nn.MaxPool2d(2, 2): the libg2s kernels on CUDA float32 maps with even H and W % 8 == 0."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0
+            and mod.kernel_size in (2, (2, 2)) and mod.stride in (2, (2, 2)) and mod.padding in (0, (0, 0))
+            and not mod.ceil_mode and mod.dilation in (1, (1, 1))):
+        return _MaxPool2x2.apply(x)
+    return mod(x)
+
+
 class VGG16Features(nn.Module):
     """relu1_2, relu2_2, relu3_3, relu4_3, relu5_3 (pretrained_networks.py:97-135)."""
 
@@ -86,7 +119,7 @@ class VGG16Features(nn.Module):
                     if isinstance(mod, nn.Conv2d):
                         x = conv_bias_relu(x, mod.weight, mod.bias)
                     elif isinstance(mod, nn.MaxPool2d):
-                        x = mod(x)
+                        x = max_pool_2x2(mod, x)
             else:
                 x = getattr(self, f"slice{si + 1}")(x)
             outs.append(x)

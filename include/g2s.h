@@ -111,6 +111,13 @@ int g2s_fused_bias_act(const void *x, const void *bias, const void *ref, void *y
                        int64_t step_b, int64_t size_b, int act, int grad, float alpha,
                        float scale, int dtype, g2s_stream_t stream);
 
+/* nn.MaxPool2d(2, 2) of the VGG16 trunk (lpips/pretrained_networks.py:97-135): x [planes, H, W] ->
+ * y [planes, H/2, W/2]; backward from the saved INPUT (first maximum of a window in row-major order
+ * wins, NaN wins: torch's rule), gx fully written.  H even, W a multiple of 8, 16-byte aligned. */
+int g2s_maxpool2x2_fwd(const float *x, float *y, int64_t planes, int H, int W, g2s_stream_t stream);
+int g2s_maxpool2x2_bwd(const float *x, const float *gy, float *gx, int64_t planes, int H, int W,
+                       g2s_stream_t stream);
+
 /* Residual joins of the frozen nets in one pass: y = (a + b + bias[c]) * scale, c = (i / hw) % C.
  * ToRGB: conv + bias + upsample(skip) (stylegan2-pytorch/model.py:371-377); discriminator ResBlock:
  * (out + skip) / sqrt(2) (model.py:693-697).  a, b, y [n] f32; b and bias [C] may be NULL. */

@@ -644,3 +644,24 @@ def test_add_bias_scale_matches_torch(g2s, shape):
         ins = [t for t in (a, b, bias) if t is not None]
         for got, want in zip(torch.autograd.grad(y, ins, g), torch.autograd.grad(ref, ins, g)):
             torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(9, 64, 128, 128), (2, 5, 6, 16), (1, 3, 2, 8)])
+def test_maxpool2x2_equals_torch(g2s, shape):
+    """g2s_maxpool2x2_fwd / _bwd against nn.MaxPool2d(2, 2) (the VGG16 trunk's pools, lpips/
+    pretrained_networks.py:97-135): values and gradient, bit for bit — including the windows of equal
+    values a ReLU feeds it (the first maximum in row-major order takes the gradient) and NaNs."""
+    from gan2shape_amd.lpips import max_pool_2x2
+    torch.manual_seed(2)
+    x = torch.relu(torch.randn(shape, device="cuda"))        # ~half the windows contain ties at 0
+    x[..., ::3, ::5] = 1.5                                       # more ties, away from zero
+    if x.numel() > 64:
+        x.view(-1)[7] = float("nan")
+    pool = torch.nn.MaxPool2d(2, 2)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y, ref = max_pool_2x2(pool, xa), pool(xb)
+    assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
+    g = torch.randn_like(ref)
+    (ga,), (gb,) = torch.autograd.grad(y, xa, g), torch.autograd.grad(ref, xb, g)
+    assert torch.equal(ga, gb)
