@@ -203,13 +203,14 @@ class PerceptualLoss(nn.Module):
         self.net.eval()
 
     def load_lin_weights(self, path):
-        sd = torch.load(path, map_location="cpu", weights_only=True)
+        """`lpips/weights/v0.1/vgg.pth` (or the same five tensors as a dict)."""
+        sd = path if isinstance(path, dict) else torch.load(path, map_location="cpu", weights_only=True)
         missing = self.net.load_state_dict(sd, strict=False)
         assert not [k for k in missing.unexpected_keys if k.startswith("lin")], missing
 
     def load_vgg_features(self, path):
         """A torchvision vgg16 state dict ('features.<idx>.weight') or its `.features` sub-dict."""
-        sd = torch.load(path, map_location="cpu", weights_only=True)
+        sd = path if isinstance(path, dict) else torch.load(path, map_location="cpu", weights_only=True)
         sd = {k.replace("features.", ""): v for k, v in sd.items() if "classifier" not in k}
         own = {}
         for si, convs in enumerate(_VGG_SLICES):

@@ -540,6 +540,58 @@ def trainer_golden():
     np.savez_compressed(os.path.join(OUT, "trainer.npz"), **out)
 
 
+def lpips_golden():
+    """The reference's PerceptualLoss(model='net-lin', net='vgg') (lpips/__init__.py:12-39 ->
+    dist_model.py:28-99 -> networks_basic.py:27-110 PNetLin / ScalingLayer / NetLinLayer /
+    spatial_average, pretrained_networks.py:97-135 vgg16 slices) run on the CPU with its own
+    `weights/v0.1/vgg.pth` linear layers.  Absent offline: skimage and IPython (import-only
+    placeholders — nothing of them is called on this path) and torchvision; the placeholder
+    `torchvision.models.vgg16().features` is tests/model_cases.vgg16_features (torchvision's layout,
+    SEEDED weights), so the reference's own slice indices define the five taps.  What this pins:
+    scaling layer, slice taps, channel normalisation, squared difference, 1x1 `lin` layers, spatial
+    mean, argument order and the gradient w.r.t. the prediction.  NOT pinned: torchvision's
+    pretrained VGG16 weights (not in the reference, not downloadable)."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import model_cases as mc
+    for name in ("skimage", "skimage.color", "skimage.transform", "IPython", "torchvision", "torchvision.models"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["skimage"].color, sys.modules["skimage"].transform = sys.modules["skimage.color"], sys.modules["skimage.transform"]
+    sys.modules["IPython"].embed = lambda *a, **k: None
+    tvm = sys.modules["torchvision.models"]
+    sys.modules["torchvision"].models = tvm
+    seed = mc.LPIPS_CFG["vgg_seed"]
+    tvm.vgg16 = lambda pretrained=True, **k: types.SimpleNamespace(features=mc.vgg16_features(seed))
+    sys.path.insert(0, SG2)
+    import lpips as ref_lpips
+    P = ref_lpips.PerceptualLoss(model='net-lin', net='vgg', use_gpu=False)
+    net = P.model.net
+    assert not net.training and net.version == '0.1' and net.lpips and not net.spatial
+    out = {}
+    for k in range(5):  # the five learned 1x1 layers of weights/v0.1/vgg.pth (1472 numbers): data
+        out[f"lin{k}"] = np_(getattr(net, f"lin{k}").model[1].weight)
+    for name, (B, S, s_in) in mc.LPIPS_CFG["cases"].items():
+        pred, target = mc.lpips_inputs(B, S, s_in)
+        pred = pred.requires_grad_(True)
+        val = P(pred, target)
+        cot = torch.linspace(0.5, 1.5, B).view(B, 1, 1, 1)
+        (gp,) = torch.autograd.grad((val * cot).sum(), pred)
+        _, per_layer = net.forward(target, pred.detach(), retPerLayer=True)
+        out[f"{name}.val"], out[f"{name}.gpred"] = np_(val), np_(gp)
+        out[f"{name}.per_layer"] = np.stack([np_(r).reshape(B) for r in per_layer])
+        # the reference in float64: measures the reference's own fp32 error, so the GPU bound is
+        # derived rather than guessed
+        P64 = ref_lpips.PerceptualLoss(model='net-lin', net='vgg', use_gpu=False)
+        P64.model.net.double()
+        p64 = pred.detach().double().requires_grad_(True)
+        v64 = P64(p64, target.double())
+        (g64,) = torch.autograd.grad((v64 * cot.double()).sum(), p64)
+        out[f"{name}.val64"], out[f"{name}.gpred64"] = np_(v64), np_(g64).astype(np.float32)
+        out[f"{name}.ref_fp32_err"] = np.array([float((val.double() - v64).abs().max() / v64.abs().max()),
+                                                float((gp.double() - g64).norm() / g64.norm())])
+    np.savez_compressed(os.path.join(OUT, "lpips.npz"), **out)
+
+
 class _Quiet:
     """tqdm stand-in: iterable with the two methods trainer.py calls on it."""
     def __init__(self, it):
@@ -656,6 +708,7 @@ if __name__ == "__main__":
     model_golden()
     steps_golden()
     trainer_golden()
+    lpips_golden()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -101,6 +101,46 @@ def fake_perceptual(pred, target):
     return (d ** 2).mean((1, 2, 3)).view(-1, 1, 1, 1) + (d.abs() ** 1.5).mean((1, 2, 3)).view(-1, 1, 1, 1)
 
 
+# torchvision.models.vgg16().features (configuration "D" of Simonyan & Zisserman): 13 conv3x3 + ReLU
+# pairs and 5 max pools = 31 modules; the reference's lpips/pretrained_networks.py:97-135 slices it
+# at 4 / 9 / 16 / 23 / 30.  torchvision (and its pretrained download) is absent offline, so both the
+# reference run of make_golden.lpips_golden and the tests use this seeded trunk.
+VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+
+
+def vgg16_features(seed):
+    """A 31-module nn.Sequential with torchvision's vgg16().features layout and seeded weights:
+    conv weights ~ N(0, 2 / fan_in) (keeps the ReLU activations' scale through 13 layers), biases
+    0.05 N, drawn in module order."""
+    g = torch.Generator().manual_seed(seed)
+    layers, cin = [], 3
+    for v in VGG16_CFG:
+        if v == 'M':
+            layers.append(torch.nn.MaxPool2d(kernel_size=2, stride=2))
+            continue
+        conv = torch.nn.Conv2d(cin, v, kernel_size=3, padding=1)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+            conv.bias.copy_(torch.randn(v, generator=g) * 0.05)
+        layers += [conv, torch.nn.ReLU(inplace=True)]
+        cin = v
+    return torch.nn.Sequential(*layers)
+
+
+LPIPS_CFG = dict(vgg_seed=61, cases={"b1_128": (1, 128, 62), "b9_64": (9, 64, 63)})
+
+
+def lpips_inputs(B, S, seed):
+    """(pred, target) in [-1, 1]: smooth images plus noise, target = a perturbed pred so that the
+    distance is in LPIPS' working range."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.tanh(F.interpolate(torch.randn(B, 3, S // 8, S // 8, generator=g), scale_factor=8, mode="bilinear",
+                                    align_corners=False))
+    pred = (base + 0.1 * torch.randn(B, 3, S, S, generator=g)).clamp(-1, 1)
+    target = (base.roll(3, 3) * 0.8 + 0.15 * torch.randn(B, 3, S, S, generator=g)).clamp(-1, 1)
+    return pred, target
+
+
 STEP_CFG = dict(image_size=128, gan_size=128, z_dim=512, channel_multiplier=1, n_proj=2,
                 seeds=dict(G=41, D=42, lighting=43, viewpoint=44, depth=45, albedo=46, offset_encoder=47))
 

@@ -411,6 +411,40 @@ def test_lpips_state_dict_keys_match_reference_weight_file():
     assert p(a, b).shape == (1, 1, 1, 1) and p(a, b).item() > 0
 
 
+def seeded_lpips(golden_lpips, device="cpu"):
+    """This package's PerceptualLoss with the fixture's trunk (tests/model_cases.vgg16_features) and
+    the reference's five `lin` layers as stored in tests/golden/lpips.npz."""
+    import model_cases as mc
+    from gan2shape_amd.lpips import PerceptualLoss
+    p = PerceptualLoss()
+    p.load_vgg_features({f"features.{k}": v for k, v in mc.vgg16_features(mc.LPIPS_CFG["vgg_seed"]).state_dict().items()})
+    p.load_lin_weights({f"lin{k}.model.1.weight": torch.from_numpy(golden_lpips[f"lin{k}"]) for k in range(5)})
+    return p.to(device).eval()
+
+
+@pytest.mark.parametrize("case", ["b1_128", "b9_64"])
+def test_lpips_vs_reference_run(golden, case):
+    """PerceptualLoss (host form, CPU) against the reference's own PerceptualLoss('net-lin', 'vgg')
+    run (lpips/__init__.py:12-39, networks_basic.py:27-110, pretrained_networks.py:97-135) on the
+    seeded trunk: value, per-layer terms and the gradient w.r.t. the prediction.  torchvision's
+    pretrained VGG16 weights themselves stay unpinned (absent offline)."""
+    import model_cases as mc
+    g = golden("lpips")
+    p = seeded_lpips(g)
+    B, S, seed = mc.LPIPS_CFG["cases"][case]
+    pred, target = mc.lpips_inputs(B, S, seed)
+    pred.requires_grad_(True)
+    val = p(pred, target)
+    assert val.shape == (B, 1, 1, 1)
+    np.testing.assert_allclose(val.detach().numpy(), g[f"{case}.val"], rtol=2e-5)
+    cot = torch.linspace(0.5, 1.5, B).view(B, 1, 1, 1)
+    (gp,) = torch.autograd.grad((val * cot).sum(), pred)
+    ref = g[f"{case}.gpred64"].astype(np.float64)
+    err = np.linalg.norm(gp.numpy() - ref) / np.linalg.norm(ref)
+    # the reference's own fp32 run is ref_fp32_err[1] away from its float64 run (ReLU / max-pool ties)
+    assert err <= max(3 * g[f"{case}.ref_fp32_err"][1], 2e-5), err
+
+
 # ----------------------------------------------------------------------------- sharding
 def test_shard_indices_partition():
     from gan2shape_amd.trainer import shard_indices
