@@ -537,6 +537,20 @@ def trainer_golden():
         t.fit(mc.toy_dataset(), stages=mc.TOY_STAGES)
     out = {"log": np.array(t.model.log, np.float64),
            "params": np_(torch.cat([p.reshape(-1) for p in t.model.parameters()]))}
+
+    # ---- the joint loop of BASELINE config 4: the reference's GeneralizingTrainer2.fit
+    # (trainer.py:338-479 on GeneralizingTrainer.pretrain_on_prior :296-335) over 5 images in batches
+    # of 2 (last batch ragged), 2 epochs: every call (kind, loss, batch size, digest of the
+    # hand-off it received) and the final parameters
+    class ImagePrior(FixedPrior):
+        def __call__(self, image, *a, **k):
+            return mc.toy_prior(image)
+    ref_trainer.PriorGenerator = ImagePrior
+    with _cuda_is_identity():
+        t = ref_trainer.GeneralizingTrainer2(mc.ToyJointModel, dict(mc.TOY_JOINT_CFG))
+        t.fit(mc.toy_dataset(5), stages=mc.TOY_JOINT_STAGES, batch_size=2)
+    out["joint.log"] = np.array(t.model.log, np.float64)
+    out["joint.params"] = np_(torch.cat([p.reshape(-1) for p in t.model.parameters()]))
     np.savez_compressed(os.path.join(OUT, "trainer.npz"), **out)
 
 

@@ -205,6 +205,54 @@ class ToyStepModel(torch.nn.Module):
         return loss, None
 
 
+class ToyJointModel(ToyStepModel):
+    """The same toy nets behind the 6-tuple `collected` the joint trainers unpack
+    (trainer.py:227,391: normals, lights_a, lights_b, albedos, depths, canon_masks; model.py:168-172:
+    canon_mask is None for one image, [None] * B for a batch).  The log also records the batch
+    size of every call and a digest of the hand-off a step received."""
+
+    def depth_net_forward(self, inputs, prior):
+        d = self.depth_net(self._feat(inputs))
+        loss = ((d - d.mean()) ** 2).mean() + ((d.mean((1,)) - prior.mean((1, 2))) ** 2).mean()
+        self.log.append((0, float(loss.detach()), len(inputs), 0.0))
+        return loss, d
+
+    def forward_step1(self, images, latents, collected, **kw):
+        assert collected is None
+        a = self.albedo_net(self._feat(images))
+        d = self.depth_net(self._feat(images)).detach()
+        loss = ((a - d) ** 2).mean() + 0.1 * (a * latents[:, :4]).mean()
+        self.log.append((1, float(loss.detach()), len(images), 0.0))
+        z = a.detach().sum(1, keepdim=True)
+        mask = None if len(images) == 1 else [None] * len(images)
+        return loss, (a.detach() * 2, z, -z, a.detach(), d, mask)
+
+    def forward_step2(self, image, latent, collected, n_proj_samples=8, **kw):
+        normal, la, lb, a, d, mask = collected
+        assert len(image) == 1 and a.shape[0] == 1 and mask is None
+        e = self.offset_encoder_net(self._feat(image))
+        loss = ((e - a) ** 2).mean() + 0.01 * n_proj_samples * (e * d).mean() + 0.001 * (e * (normal + la + lb)).mean()
+        self.log.append((2, float(loss.detach()), len(image), float(a.sum() + d.sum())))
+        return loss, (e.detach(), e.detach() > 0)
+
+    def forward_step3(self, image, latent, collected, **kw):
+        e, _mask = collected
+        out = sum(getattr(self, f"{n}_net")(self._feat(image)) for n in ("lighting", "viewpoint", "depth", "albedo"))
+        loss = ((out - e) ** 2).mean()
+        self.log.append((3, float(loss.detach()), len(image), float(e.sum())))
+        return loss, None
+
+
+TOY_JOINT_STAGES = [{'step1': 2, 'step2': 2, 'step3': 3}]
+TOY_JOINT_CFG = {"image_size": 8, "category": "face", "n_proj_samples": 3, "n_epochs_prior": 2,
+                 "n_epochs_generalized": 2, "prior_name": "ellipsoid"}
+
+
+def toy_prior(image):
+    """Per-image stand-in for PriorGenerator (needs parsing-net checkpoints): (1, 8, 8)."""
+    return 0.95 + 0.02 * torch.tanh(image.reshape(-1)[:64]).reshape(1, 8, 8)
+
+
 def toy_dataset(n=2):
     g = torch.Generator().manual_seed(9)
     return [(torch.randn(3, 8, 8, generator=g), torch.randn(8, generator=g), i) for i in range(n)]

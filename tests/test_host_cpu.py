@@ -355,6 +355,32 @@ def test_trainer_fit_follows_reference_loop(golden):
     np.testing.assert_allclose(params, g["params"], rtol=1e-6, atol=1e-7)
 
 
+def test_joint_trainer_fit_follows_reference_run(golden):
+    """GeneralizingTrainer2.fit (BASELINE config 4's loop) against the reference's own
+    GeneralizingTrainer2.fit run (GAN2Shape/trainer.py:338-479, pretrain_on_prior :296-335) on the toy
+    model, 5 images in batches of 2 (ragged last batch), 2 epochs: order and batch size of every
+    call, the hand-off each step received, every loss, the final parameters."""
+    from gan2shape_amd.trainer import GeneralizingTrainer2
+    from model_cases import TOY_JOINT_CFG, TOY_JOINT_STAGES, ToyJointModel, toy_dataset, toy_prior
+    g = golden("trainer")
+
+    class ImagePrior:
+        def __call__(self, image, device="cpu"):
+            return toy_prior(image)
+    t = GeneralizingTrainer2(ToyJointModel, dict(TOY_JOINT_CFG), device="cpu")
+    t.prior_generator = ImagePrior()
+    n = t.fit(toy_dataset(5), stages=TOY_JOINT_STAGES, batch_size=2)
+    log, ref = np.array(t.model.log, np.float64), g["joint.log"]
+    assert log.shape == ref.shape
+    assert n == int((ref[:, 0] > 0).sum())
+    np.testing.assert_array_equal(log[:, 0], ref[:, 0])               # call order
+    np.testing.assert_array_equal(log[:, 2], ref[:, 2])               # batch size of every call
+    np.testing.assert_allclose(log[:, 3], ref[:, 3], rtol=1e-5)       # the `collected` each step received
+    np.testing.assert_allclose(log[:, 1], ref[:, 1], rtol=1e-5)       # every loss
+    params = torch.cat([p.reshape(-1) for p in t.model.parameters()]).detach().numpy()
+    np.testing.assert_allclose(params, g["joint.params"], rtol=1e-5, atol=1e-6)
+
+
 # ----------------------------------------------------------------------------- reference (live)
 def _ref_sg2():
     if SG2 not in sys.path:
