@@ -9,7 +9,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
+SANITIZE = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+
+
+def build_sanitized(out_dir):
+    """The same sources under AddressSanitizer + UBSan (CPU only; tests/test_sanitizers_cpu.py loads
+    it through G2S_ORACLE_LIB in a child process that preloads libasan)."""
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libg2s_oracle_san.so")
+    subprocess.check_call(["gcc"] + SANITIZE + ["-fPIC", "-ffp-contract=off", "-fopenmp", "-shared", "-o", so,
+                                                os.path.join(_HERE, "g2s_oracle.c"), "-lm"])
+    return so
+
+
 def build(force=False):
+    if os.environ.get("G2S_ORACLE_LIB"):     # a sanitizer build made by build_sanitized()
+        return os.environ["G2S_ORACLE_LIB"]
     so = os.path.join(_HERE, "libg2s_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("g2s_oracle.c", "raster_body.inc")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

@@ -23,8 +23,12 @@ FAR = 100.0
 def emul():
     os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
     so = os.path.join(HERE, "_build", "libraster_emul.so")
-    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", so,
-                           os.path.join(HERE, "raster_tile_emulation.cpp")])
+    flags = ["-O2"]
+    if os.environ.get("G2S_ORACLE_LIB"):   # the sanitizer pass (tests/test_sanitizers_cpu.py)
+        so = os.path.join(HERE, "_build", "libraster_emul_san.so")
+        flags = capi.SANITIZE
+    subprocess.check_call(["g++"] + flags + ["-fPIC", "-shared", "-ffp-contract=off", "-o", so,
+                                             os.path.join(HERE, "raster_tile_emulation.cpp")])
     return C.CDLL(so)
 
 
