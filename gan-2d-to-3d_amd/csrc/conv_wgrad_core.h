@@ -136,6 +136,7 @@ static inline int wgrad_plan(const float *A, const float *G, float *dw, int B, i
     p.ktiles = cdiv(p.K, WG_BK);
     tiles = cdiv(Ca, WG_BM) * cdiv(p.N, WG_BN);
     split = std::max(1, std::min(p.ktiles, cdiv(768, tiles * groups)));
+    if (deterministic()) split = 1;   // the whole pixel reduction in one workgroup: fixed order, no atomics
     p.per = cdiv(p.ktiles, split);
     split = cdiv(p.ktiles, p.per);
     p.atomic = split > 1;

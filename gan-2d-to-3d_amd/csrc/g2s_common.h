@@ -10,6 +10,9 @@ namespace g2s {
 char *error_buf();                     // thread-local, defined in api.hip
 int fail(int code, const char *fmt, ...);
 
+// g2s_set_deterministic (api.hip): launches choose partitions whose fp32 sums have a fixed order.
+bool deterministic();
+
 inline hipStream_t as_stream(g2s_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Checks the launch (not the execution: no synchronisation inside the library).

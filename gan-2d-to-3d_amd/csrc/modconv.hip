@@ -791,6 +791,7 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
     while ((long)tiles * d.ncls * splitk < 512 && kt_min / (splitk * 2) >= 8 && splitk < 64) splitk *= 2;
     if (tuned_splitk > 0) splitk = tuned_splitk;
     if (g_force_splitk > 0) splitk = g_force_splitk;
+    if (deterministic()) splitk = 1;   // no float atomics: one workgroup owns every output element
     splitk = std::max(1, std::min(splitk, kt_min));
     dim3 grid(tiles, splitk, d.ncls);
     // A bias / activation epilogue needs the complete sum: with split-K it runs as a second,

@@ -570,6 +570,13 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
             d.part_n = (long)y_floats;
         }
     }
+    if (deterministic() && partial_sums && !use_part) {
+        // partial sums would meet by float atomics (no workspace): whole tiles instead
+        splitk = 1;
+        grid_x = tiles;
+        d.upw = 0;
+        partial_sums = false;
+    }
     const bool deferred = partial_sums && !streamk_part && (bias != nullptr || act != 0);
     if (deferred) {
         d.bias = nullptr;

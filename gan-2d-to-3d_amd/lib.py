@@ -18,6 +18,8 @@ _p, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
 SIGNATURES = {
     "g2s_abi_version": (_i, []),
     "g2s_last_error": (C.c_char_p, []),
+    "g2s_set_deterministic": (_i, [_i]),
+    "g2s_get_deterministic": (_i, []),
     "g2s_raster_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "g2s_raster_tune": (_i, [_i]),
     "g2s_raster_depth_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p, _f, _i, _i, _f, _f, _p, _p, _p, _p, _sz, _p]),
@@ -88,6 +90,16 @@ def load():
             raise G2SError(f"libg2s ABI version {lib.g2s_abi_version()} != 1")
         _lib = lib
     return _lib
+
+
+def set_deterministic(on=True):
+    """g2s_set_deterministic (include/g2s.h): reproducible launch partitions for the whole process —
+    bit-identical network forwards from run to run, at the cost of the split-K speedups.  Returns
+    the previous setting."""
+    L = load()
+    prev = bool(L.g2s_get_deterministic())
+    check(L.g2s_set_deterministic(int(bool(on))))
+    return prev
 
 
 def check(rc):

@@ -10,10 +10,10 @@
  *     never synchronises, never throws);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *   - returns G2S_OK (0) or a negative error code; g2s_last_error() gives a thread-local message;
- *   - re-entrant; no process-global mutable state.  Thread-local state: the error string and the
- *     two tuning overrides g2s_modconv_tune / g2s_raster_tune (off by default; they select among
- *     launch configurations that produce the same results, and only affect the calling thread).
- *     No environment variable is read.
+ *   - re-entrant.  Thread-local state: the error string and the two tuning overrides
+ *     g2s_modconv_tune / g2s_raster_tune (off by default; they select among launch configurations
+ *     that produce the same results, and only affect the calling thread).  Process-global state:
+ *     ONE flag, g2s_set_deterministic (off by default).  No environment variable is read.
  */
 #ifndef G2S_H
 #define G2S_H
@@ -39,6 +39,19 @@ typedef void *g2s_stream_t; /* hipStream_t */
 
 int g2s_abi_version(void);
 const char *g2s_last_error(void);
+
+/* Reproducible launches (no reference counterpart: torch.use_deterministic_algorithms is the
+ * analogue a maintainer would reach for).  on = 1: every convolution launch of the process takes a
+ * partition in which ONE workgroup owns each output element — direct kernel split-K 1
+ * (csrc/modconv.hip), weight-gradient GEMM without its pixel split (csrc/conv_wgrad_core.h),
+ * Winograd split-K / stream-K only with stored slices (workspace given), else whole tiles — so the
+ * forward values of every network are bit-identical from run to run and independent of how many
+ * workgroups race.  Slower (small layers no longer fill 256 CUs); results differ from the default
+ * mode by fp32 summation order only.  What remains order-dependent at the 1e-7 level: the scalar
+ * loss accumulators and the gradient scatter of the rasterizer / geometry backward kernels (float
+ * atomics over tiles).  Takes effect for launches issued after the call, from any thread. */
+int g2s_set_deterministic(int on);
+int g2s_get_deterministic(void);
 
 /* ------------------------------------------------------------------------------------------
  * Differentiable depth rasterizer.

@@ -503,10 +503,19 @@ def steps_golden():
         out["s2.projected"], out["s2.mask"] = np_(c2[0]), np_(c2[1])
 
         # ---- step 3 (model.py:225-280)
-        loss3, _ = M.forward_step3(image, latent, c2)
-        loss3.backward()
+        # the tensors where the loss meets the geometry chain, with d loss / d tensor: the view vectors
+        # ([0]: the image's own, inner step-1 pass; [1]: the n projected samples'), the canonical depth,
+        # the warped depth maps of both rasterizer calls (B = 1 and B = n)
+        with mc.capture_step_tensors(M) as cap:
+            loss3, _ = M.forward_step3(image, latent, c2)
+            loss3.backward()
         grad_norms("s3")
         out["s3.loss"] = np_(loss3)
+        assert len(cap.view) == 2 and len(cap.depth) == 1 and len(cap.recon_depth) == 2
+        for i in range(2):
+            out[f"s3.view{i}"], out[f"s3.gview{i}"] = np_(cap.view[i]), np_(cap.view[i].grad)
+            out[f"s3.recon_depth{i}"], out[f"s3.grecon{i}"] = np_(cap.recon_depth[i]), np_(cap.recon_depth[i].grad)
+        out["s3.depth"], out["s3.gdepth"] = np_(cap.depth[0]), np_(cap.depth[0].grad)
     np.savez_compressed(os.path.join(OUT, "steps.npz"), **{k: (v.astype(np.float32) if v.dtype == np.float64 and v.ndim else v)
                                                             for k, v in out.items()})
 

@@ -145,6 +145,42 @@ STEP_CFG = dict(image_size=128, gan_size=128, z_dim=512, channel_multiplier=1, n
                 seeds=dict(G=41, D=42, lighting=43, viewpoint=44, depth=45, albedo=46, offset_encoder=47))
 
 
+class capture_step_tensors:
+    """Record the tensors where a step's loss meets the geometry chain, on the REFERENCE's GAN2Shape
+    (make_golden.steps_golden) and on this package's alike: every view vector handed to the view
+    transformation (reference: get_view_transformation, model.py:119,246; here: _set_view), every
+    clamped canonical depth (get_clamped_depth, model.py:108) and every warped depth map
+    (renderer.warp_canon_depth, renderer.py:116-125), each with `retain_grad()` so that after
+    backward() `.grad` holds d loss / d tensor.  Lists are in call order."""
+
+    def __init__(self, model):
+        self.m, self.view, self.depth, self.recon_depth = model, [], [], []
+
+    def __enter__(self):
+        m = self.m
+        view_fn = "_set_view" if hasattr(m, "_set_view") else "get_view_transformation"
+        self._orig = [(m, view_fn, getattr(m, view_fn)), (m, "get_clamped_depth", m.get_clamped_depth),
+                      (m.renderer, "warp_canon_depth", m.renderer.warp_canon_depth)]
+
+        def keep(t, where):
+            if t.requires_grad:
+                t.retain_grad()
+            where.append(t)
+            return t
+        (_, _, view0), (_, _, clamp0), (_, _, warp0) = self._orig
+        setattr(m, view_fn, lambda view, *a, **k: view0(keep(view, self.view), *a, **k))
+        m.get_clamped_depth = lambda *a, **k: keep(clamp0(*a, **k), self.depth)
+        m.renderer.warp_canon_depth = lambda *a, **k: keep(warp0(*a, **k), self.recon_depth)
+        return self
+
+    def __exit__(self, *exc):
+        for obj, name, fn in self._orig:
+            try:
+                delattr(obj, name)      # drop the instance attribute: the class method shows again
+            except AttributeError:
+                setattr(obj, name, fn)
+
+
 def prepare_generator(G, seed, fill_deterministic):
     """fill_deterministic leaves the mapping network's weights at N(0, 1) although EqualLinear keeps
     them at N(0, 1) / lr_mul (lr_mul = 0.01): restore that scale so that latent offsets matter."""
