@@ -62,6 +62,12 @@ class GAN2Shape(nn.Module):
 
         self.image_size = config.get('image_size')
         self.collected = None
+        # `deterministic: true` (added; no reference counterpart): reproducible launch partitions for
+        # the whole process (include/g2s.h g2s_set_deterministic) — bit-identical network forwards run
+        # to run, slower.  Absent = leave the process setting alone.
+        if config.get('deterministic') is not None and self.device.type == "cuda":
+            from . import lib as _lib
+            _lib.set_deterministic(bool(config['deterministic']))
         # BASELINE config 5: fp16 operands / fp32 accumulation for the frozen G / D / VGG GEMMs (a
         # process-wide switch of modconv.py; absent = the reference's fp32 arithmetic)
         if config.get('mfma_operands') is not None:

@@ -511,10 +511,11 @@ def steps_golden():
             loss3.backward()
         grad_norms("s3")
         out["s3.loss"] = np_(loss3)
-        assert len(cap.view) == 2 and len(cap.depth) == 1 and len(cap.recon_depth) == 2
+        assert len(cap.view) == 2 and len(cap.depth) == 1 and len(cap.recon_depth) == 2 and len(cap.verts) == 2
         for i in range(2):
             out[f"s3.view{i}"], out[f"s3.gview{i}"] = np_(cap.view[i]), np_(cap.view[i].grad)
             out[f"s3.recon_depth{i}"], out[f"s3.grecon{i}"] = np_(cap.recon_depth[i]), np_(cap.recon_depth[i].grad)
+            out[f"s3.gverts{i}"] = np_(cap.verts[i].grad)     # d loss / d mesh vertices: the rasterizer's backward
         out["s3.depth"], out["s3.gdepth"] = np_(cap.depth[0]), np_(cap.depth[0].grad)
     np.savez_compressed(os.path.join(OUT, "steps.npz"), **{k: (v.astype(np.float32) if v.dtype == np.float64 and v.ndim else v)
                                                             for k, v in out.items()})
@@ -712,14 +713,40 @@ def gan_golden():
     d = sg2.Discriminator(128, channel_multiplier=1)
     fill_deterministic(d, 78)
     d.eval()
+    # pre-activations of every leaky ReLU (FusedLeakyReLU: input + bias; op/fused_act.py:86-92) within
+    # fp32 rounding of zero: the units whose slope (0.2 or 1) is decided by summation order
+    near_zero = np.zeros(3, np.int64)   # |pre| < 1e-6 std, < 1e-5 std, total
+
+    def count_near_zero(mod, inp):
+        pre = (inp[0] + mod.bias.view(1, -1, 1, 1)).detach()
+        s_ = float(pre.std())
+        near_zero[:] += [int((pre.abs() < 1e-6 * s_).sum()), int((pre.abs() < 1e-5 * s_).sum()), pre.numel()]
+    hooks = [m_.register_forward_pre_hook(count_near_zero) for m_ in d.modules() if type(m_).__name__ == "FusedLeakyReLU"]
     x = torch.tanh(img.detach()[:2] / img.detach().abs().max() * 3).requires_grad_(True)
     _, feats = d(x, ftr_num=4)
+    for h_ in hooks:
+        h_.remove()
+    out["d128.near_zero_preacts"] = near_zero
     gf = [torch.randn(f.shape, generator=torch.Generator().manual_seed(10 + i)) for i, f in enumerate(feats)]
     (gx,) = torch.autograd.grad(feats, x, gf)
     out["d128.gx"] = np_(gx)
     for i, f in enumerate(feats):   # per-level summaries (the maps themselves are 8 MB): mean, abs-mean, 4x4 pooled
         out[f"d128.f{i}.pool"] = np_(torch.nn.functional.adaptive_avg_pool2d(f, 4))
         out[f"d128.f{i}.absmean"] = np_(f.abs().mean((1, 2, 3)))
+    # the same gradient through the reference module in float64, and how far the reference's OWN fp32
+    # run is from it (L2, share of elements beyond 5e-3 max, max / max): units that sit within rounding
+    # of a leaky-ReLU kink take the other slope — the GPU result is held to this measured scatter
+    d64 = sg2.Discriminator(128, channel_multiplier=1)
+    fill_deterministic(d64, 78)
+    d64 = d64.eval().double()
+    x64 = x.detach().double().requires_grad_(True)
+    _, feats64 = d64(x64, ftr_num=4)
+    (gx64,) = torch.autograd.grad(feats64, x64, [t.double() for t in gf])
+    out["d128.gx64"] = np_(gx64).astype(np.float32)
+    e = (gx.double() - gx64).abs()
+    out["d128.ref_fp32_err"] = np.array([float((gx.double() - gx64).norm() / gx64.norm()),
+                                         float((e > 5e-3 * gx64.abs().max()).double().mean()),
+                                         float(e.max() / gx64.abs().max())])
     np.savez_compressed(os.path.join(OUT, "gan128.npz"), **out)
 
 

@@ -149,28 +149,31 @@ class capture_step_tensors:
     """Record the tensors where a step's loss meets the geometry chain, on the REFERENCE's GAN2Shape
     (make_golden.steps_golden) and on this package's alike: every view vector handed to the view
     transformation (reference: get_view_transformation, model.py:119,246; here: _set_view), every
-    clamped canonical depth (get_clamped_depth, model.py:108) and every warped depth map
+    clamped canonical depth (get_clamped_depth, model.py:108), the camera-space mesh vertices handed
+    to the rasterizer (renderer.get_warped_3d_grid, renderer.py:90-95,118) and every warped depth map
     (renderer.warp_canon_depth, renderer.py:116-125), each with `retain_grad()` so that after
     backward() `.grad` holds d loss / d tensor.  Lists are in call order."""
 
     def __init__(self, model):
-        self.m, self.view, self.depth, self.recon_depth = model, [], [], []
+        self.m, self.view, self.depth, self.recon_depth, self.verts = model, [], [], [], []
 
     def __enter__(self):
         m = self.m
         view_fn = "_set_view" if hasattr(m, "_set_view") else "get_view_transformation"
         self._orig = [(m, view_fn, getattr(m, view_fn)), (m, "get_clamped_depth", m.get_clamped_depth),
-                      (m.renderer, "warp_canon_depth", m.renderer.warp_canon_depth)]
+                      (m.renderer, "warp_canon_depth", m.renderer.warp_canon_depth),
+                      (m.renderer, "get_warped_3d_grid", m.renderer.get_warped_3d_grid)]
 
         def keep(t, where):
             if t.requires_grad:
                 t.retain_grad()
             where.append(t)
             return t
-        (_, _, view0), (_, _, clamp0), (_, _, warp0) = self._orig
+        (_, _, view0), (_, _, clamp0), (_, _, warp0), (_, _, verts0) = self._orig
         setattr(m, view_fn, lambda view, *a, **k: view0(keep(view, self.view), *a, **k))
         m.get_clamped_depth = lambda *a, **k: keep(clamp0(*a, **k), self.depth)
         m.renderer.warp_canon_depth = lambda *a, **k: keep(warp0(*a, **k), self.recon_depth)
+        m.renderer.get_warped_3d_grid = lambda *a, **k: keep(verts0(*a, **k), self.verts)
         return self
 
     def __exit__(self, *exc):

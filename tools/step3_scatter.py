@@ -34,6 +34,7 @@ def one_run(m, g):
     for i in range(2):
         out[f"view{i}"], out[f"gview{i}"] = cap.view[i].detach().cpu().numpy(), cap.view[i].grad.cpu().numpy()
         out[f"recon_depth{i}"], out[f"grecon{i}"] = cap.recon_depth[i].detach().cpu().numpy(), cap.recon_depth[i].grad.cpu().numpy()
+        out[f"gverts{i}"] = cap.verts[i].grad.cpu().numpy()
     out["depth"], out["gdepth"] = cap.depth[0].detach().cpu().numpy(), cap.depth[0].grad.cpu().numpy()
     return out
 
