@@ -681,8 +681,8 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
                        const float *bias, int act, float act_alpha, float act_gain, float *y, int B,
                        int Cr, int M, int H, int W, const ConvGeom &g, int tuned_tile, int tuned_splitk,
                        g2s_stream_t stream, bool y_is_zero = false, bool f16_operands = false, int groups = 1,
-                       const WgradRider *rider = nullptr) {
-    G2S_REQUIRE(x && w && y, "x, w, y must not be NULL");
+                       const WgradRider *rider = nullptr, int *plan_needs_zero = nullptr) {
+    G2S_REQUIRE(plan_needs_zero || (x && w && y), "x, w, y must not be NULL");
     G2S_REQUIRE(B > 0 && Cr > 0 && M > 0 && H > 0 && W > 0, "sizes must be positive");
     const int k = g.k, s_ = g.stride, p_ = g.pad, KK = k * k;
     G2S_REQUIRE(k >= 1 && k <= 5, "kernel size must be 1..5 (got %d)", k);
@@ -811,6 +811,10 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
         const int kt = ktiles_of(d.Cr, d.cls[i].T);
         d.cls_splitk[i] = std::max(1, std::min(kt, (int)(((long)splitk * kt + kt_max / 2) / kt_max)));
     }
+    if (plan_needs_zero) {   // g2s_modconv_needs_zero: report, launch nothing
+        *plan_needs_zero = (split || holes) ? 1 : 0;
+        return G2S_OK;
+    }
     if ((split || holes) && !y_is_zero) {
         if (hipMemsetAsync(y, 0, (size_t)B * d.My * d.OHf * d.OWf * sizeof(float), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(y) failed");
@@ -871,7 +875,8 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
 static int modconv_launch(const float *x, const float *w, const float *in_scale,
                           const float *out_scale, const float *bias, int act, float act_alpha,
                           float act_gain, float *y, int B, int Cin, int Cout, int H, int W, int k,
-                          int mode, int transpose, g2s_stream_t stream, bool f16_operands = false) {
+                          int mode, int transpose, g2s_stream_t stream, bool f16_operands = false,
+                          bool y_is_zero = false, int *plan_needs_zero = nullptr) {
     G2S_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "sizes must be positive");
     G2S_REQUIRE(k == 1 || k == 3, "kernel size must be 1 or 3 (got %d)", k);
     G2S_REQUIRE(mode == G2S_CONV_PLAIN || mode == G2S_CONV_UP2 || mode == G2S_CONV_DOWN2,
@@ -879,8 +884,13 @@ static int modconv_launch(const float *x, const float *w, const float *in_scale,
     // fromRGB (1x1 from 3 channels over >= 64 K pixels) runs as a streaming kernel (thinconv.hip) instead
     // of an MFMA tile whose K is padding.  A forced tile keeps the call on the MFMA kernel (tests).
     if (!f16_operands && !in_scale && !out_scale && mode == G2S_CONV_PLAIN && g_force_tile == -1 &&
-        g_force_splitk == -1 && thin_conv_eligible(B, Cin, Cout, H, W, k, transpose))
+        g_force_splitk == -1 && thin_conv_eligible(B, Cin, Cout, H, W, k, transpose)) {
+        if (plan_needs_zero) {
+            *plan_needs_zero = 0;
+            return G2S_OK;
+        }
         return thin_conv_launch(x, w, bias, y, B, Cin, Cout, H, W, act, act_alpha, act_gain, stream);
+    }
     ConvGeom g{};
     g.k = k;
     g.stride = mode == G2S_CONV_PLAIN ? 1 : 2;
@@ -900,8 +910,30 @@ static int modconv_launch(const float *x, const float *w, const float *in_scale,
                 break;
             }
     return conv_launch(x, w, in_scale, out_scale, bias, act, act_alpha, act_gain, y, B,
-                       transpose ? Cout : Cin, transpose ? Cin : Cout, H, W, g, tile, splitk, stream, false,
-                       f16_operands);
+                       transpose ? Cout : Cin, transpose ? Cin : Cout, H, W, g, tile, splitk, stream, y_is_zero,
+                       f16_operands, 1, nullptr, plan_needs_zero);
+}
+
+// g2s_modconv + g2s_conv_bias_act in one entry point, with the caller's promise that y is already
+// zero (a slice of a pool cleared once per training step: the split-K / polyphase-hole paths then
+// issue no clear of their own — one graph node less per such launch).
+extern "C" int g2s_modconv_ex(const float *x, const float *w, const float *in_scale, const float *out_scale,
+                              const float *bias, float *y, int B, int Cin, int Cout, int H, int W, int k, int mode,
+                              int transpose, int act, float alpha, float gain, int y_is_zero, g2s_stream_t stream) {
+    G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
+    return modconv_launch(x, w, in_scale, out_scale, bias, act, alpha, gain, y, B, Cin, Cout, H, W, k, mode,
+                          transpose, stream, false, y_is_zero != 0);
+}
+
+// 1 if that launch adds into a cleared output (split-K slices / polyphase holes), else 0; < 0: error.
+extern "C" int g2s_modconv_needs_zero(int B, int Cin, int Cout, int H, int W, int k, int mode, int transpose,
+                                      int has_scales, int fused) {
+    int needs = 0;
+    static const float dummy = 0.0f;   // never dereferenced: the plan mode launches nothing
+    const float *sc = has_scales ? &dummy : nullptr;
+    const int rc = modconv_launch(nullptr, nullptr, sc, nullptr, fused ? &dummy : nullptr, fused ? 1 : 0, 0.0f, 1.0f,
+                                  nullptr, B, Cin, Cout, H, W, k, mode, transpose, nullptr, false, false, &needs);
+    return rc == G2S_OK ? needs : rc;
 }
 
 extern "C" int g2s_modconv_f16(const float *x, const float *w, const float *in_scale, const float *out_scale,

@@ -33,6 +33,8 @@ SIGNATURES = {
     "g2s_upfirdn2d": (_i, [_p, _p, _p] + [_i] * 14 + [_p]),
     "g2s_modconv": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "g2s_conv_bias_act": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
+    "g2s_modconv_ex": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "g2s_modconv_needs_zero": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "g2s_modconv_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
     "g2s_modconv_tune": (_i, [_i, _i]),
     "g2s_wino_weights_floats": (_sz, [_i, _i]),

@@ -16,6 +16,7 @@ import torch
 from torch.autograd import Function
 
 from . import lib as _lib
+from . import zeropool as _zp
 
 PLAIN, UP2, DOWN2 = _lib.CONV_PLAIN, _lib.CONV_UP2, _lib.CONV_DOWN2
 
@@ -168,21 +169,40 @@ def modconv_raw(x, w, in_scale, out_scale, mode, transpose):
     for name, t, c in (("in_scale", in_scale, C), ("out_scale", out_scale, cy)):
         if t is not None and (t.shape != (B, c) or t.dtype != torch.float32):
             raise RuntimeError(f"modconv: {name} must be float32 [{B}, {c}]")
-    y = torch.empty((B, cy, oh, ow), dtype=torch.float32, device=x.device)
     si = None if in_scale is None else in_scale.contiguous()
     so = None if out_scale is None else out_scale.contiguous()
-    if OPERANDS == "f16" and not w.requires_grad:
-        return _f16_launch(x, w, si, so, None, mode, transpose, 0, 0.0, 1.0, y)
-    choice = wino_choice(x, w, mode, transpose, 0)
-    if choice is not None:
+    f16 = OPERANDS == "f16" and not w.requires_grad
+    choice = None if f16 else wino_choice(x, w, mode, transpose, 0)
+    if f16 or choice is not None:
+        y = torch.empty((B, cy, oh, ow), dtype=torch.float32, device=x.device)
+        if f16:
+            return _f16_launch(x, w, si, so, None, mode, transpose, 0, 0.0, 1.0, y)
         return _wino_launch(x, w, si, so, None, transpose, 0, 0.0, 1.0, y, choice)
+    return _direct_launch(x, w, si, so, None, mode, transpose, 0, 0.0, 1.0, (B, cy, oh, ow))
+
+
+def _direct_launch(x, w, si, so, bias, mode, transpose, act, alpha, gain, out_shape):
+    """The direct implicit-GEMM kernel (g2s_modconv_ex).  Outputs of launches that add partial sums
+    (split-K slices, polyphase holes) come from the step's cleared pool when one is active."""
+    B, _, H, W = x.shape
+    Cout, Cin, k, _ = w.shape
     L = _lib.load()
+    fused = bias is not None or act != 0
+    y = None
+    if L.g2s_modconv_needs_zero(B, Cin, Cout, H, W, k, mode, int(transpose), int(si is not None or so is not None),
+                                int(fused)) == 1:
+        y = _zp.take(out_shape, x.device)
+    zeroed = y is not None
+    if y is None:
+        y = torch.empty(out_shape, dtype=torch.float32, device=x.device)
     # algorithmic FLOP: 2 * B * Cout * Cin * k^2 * (spatial positions of the un-strided side);
     # algorithmic bytes: each operand once
+    oh, ow = out_shape[2], out_shape[3]
     sp = min(H * W, oh * ow) if mode != PLAIN else oh * ow
     with profiled(2.0 * B * Cout * Cin * k * k * sp, 4.0 * (x.numel() + w.numel() + y.numel())):
-        _lib.check(L.g2s_modconv(_lib.ptr(x), _lib.ptr(w), _lib.ptr(si), _lib.ptr(so), _lib.ptr(y), B,
-                                 Cin, Cout, H, W, k, mode, int(transpose), _lib.stream()))
+        _lib.check(L.g2s_modconv_ex(_lib.ptr(x), _lib.ptr(w), _lib.ptr(si), _lib.ptr(so), _lib.ptr(bias), _lib.ptr(y),
+                                    B, Cin, Cout, H, W, k, mode, int(transpose), int(act), float(alpha), float(gain),
+                                    int(zeroed), _lib.stream()))
     return y
 
 
@@ -345,17 +365,15 @@ class ConvBiasActFunction(Function):
         B, Cin, H, W = x.shape
         Cout, _, k, _ = w.shape
         oh, ow = out_size(H, k, mode), out_size(W, k, mode)
-        y = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device)
-        choice = wino_choice(x, w, mode, 0, 1)
-        if OPERANDS == "f16":
-            _f16_launch(x, w, None, None, bias, mode, 0, 1, alpha, gain, y)
-        elif choice is not None:
-            _wino_launch(x, w, None, None, bias, 0, 1, alpha, gain, y, choice)
+        choice = None if OPERANDS == "f16" else wino_choice(x, w, mode, 0, 1)
+        if OPERANDS == "f16" or choice is not None:
+            y = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device)
+            if OPERANDS == "f16":
+                _f16_launch(x, w, None, None, bias, mode, 0, 1, alpha, gain, y)
+            else:
+                _wino_launch(x, w, None, None, bias, 0, 1, alpha, gain, y, choice)
         else:
-            L = _lib.load()
-            with profiled(2.0 * B * Cout * Cin * k * k * oh * ow, 4.0 * (x.numel() + w.numel() + y.numel())):
-                _lib.check(L.g2s_conv_bias_act(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B, Cin,
-                                               Cout, H, W, k, mode, 1, float(alpha), float(gain), _lib.stream()))
+            y = _direct_launch(x, w, None, None, bias, mode, 0, 1, alpha, gain, (B, Cout, oh, ow))
         ctx.save_for_backward(w, y)
         ctx.cfg = (mode, float(alpha), float(gain))
         return y

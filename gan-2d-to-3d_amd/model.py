@@ -29,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.distributions.multivariate_normal import MultivariateNormal
 
-from . import networks, utils
+from . import networks, utils, zeropool
 from .losses import DiscriminatorLoss, PhotometricLoss, SmoothLoss
 from .lpips import PerceptualLoss
 from .renderer import Renderer
@@ -238,6 +238,8 @@ class GAN2Shape(nn.Module):
         samples through V / L and through LPIPS; the arithmetic per sample is unchanged)."""
         b = 1
         h, w = self.image_size, self.image_size
+        if step1 and images.is_cuda:   # a step of its own (forward_step3 begins the pool for its inner call)
+            zeropool.begin("eval" if eval else 1, images.device)
 
         def frozen_if_step1(net, x):  # model.py:99-122: only the albedo net learns in step 1
             def job():
@@ -301,6 +303,8 @@ class GAN2Shape(nn.Module):
     def forward_step2(self, image, latent, collected, n_proj_samples=8, **kwargs):
         """model.py:175-223: optimise the offset encoder so that G reproduces the pseudo samples."""
         F1_d = 2  # number of mapping network layers used to regularize the latent offset
+        if image.is_cuda:
+            zeropool.begin(2, image.device)
         *tensors, canon_mask = collected
         normal, light_a, light_b, albedo, depth = [t.detach() for t in tensors]
 
@@ -385,6 +389,8 @@ class GAN2Shape(nn.Module):
     def forward_step3(self, images, latents, collected, **kwargs):
         """model.py:225-280: optimise V, L, D, A on the image and its projected samples."""
         projected_samples, masks = collected
+        if images.is_cuda:
+            zeropool.begin(3, images.device)
         # the reference draws (and discards) a permutation here (model.py:231-233): keep the draw so
         # that a seeded run consumes the CPU generator identically
         torch.randperm(len(projected_samples))

@@ -1,0 +1,56 @@
+"""One cleared pool per training step for the outputs of launches that ADD partial sums.
+
+The split-K slices of the direct convolution kernel (small layers: too few tiles for 256 CUs) and
+the polyphase classes that leave holes add into an output that must start at zero.  The library
+clears such an output itself (hipMemsetAsync) — one more graph node per launch, 36 of step 1's 319.
+Here each step kind clears ONE buffer at its start and hands out slices (g2s_modconv_ex,
+y_is_zero = 1).  The buffer is a fresh tensor of the caching allocator per step (sized by what the
+previous step of that kind asked for), slices are ordinary views that keep it alive, nothing is ever
+handed out twice: no lifetime hazards, and inside a captured HIP graph it lives in the graph's
+private pool like every other tensor of the step.  A request that does not fit falls back to the
+library's own clear."""
+import torch
+
+_state = {"buf": None, "off": 0, "key": None}
+_demand = {}          # step kind -> floats requested during the last step of that kind
+_want = {}            # running count of the current step
+
+
+def _pad(n):
+    return (n + 63) & ~63
+
+
+def begin(key, device):
+    """Start of a training step of kind `key`: clear a pool as large as that kind's last demand."""
+    cur = _state["key"]
+    if cur is not None:
+        _demand[cur] = _want.get(cur, 0)
+    _want[key] = 0
+    n = _demand.get(key, 0)
+    _state["key"] = key
+    _state["off"] = 0
+    _state["buf"] = torch.zeros(n, dtype=torch.float32, device=device) if n else None
+
+
+def end():
+    cur = _state["key"]
+    if cur is not None:
+        _demand[cur] = _want.get(cur, 0)
+    _state.update(buf=None, off=0, key=None)
+
+
+def take(shape, device):
+    """A zero-filled tensor of `shape` carved from the step's pool, or None (no step active / first
+    step of its kind / does not fit)."""
+    key = _state["key"]
+    if key is None:
+        return None
+    n = 1
+    for d in shape:
+        n *= int(d)
+    _want[key] = _want.get(key, 0) + _pad(n)
+    buf, off = _state["buf"], _state["off"]
+    if buf is None or buf.device != device or off + n > buf.numel():
+        return None
+    _state["off"] = off + _pad(n)
+    return buf[off:off + n].view(shape)

@@ -196,6 +196,20 @@ int g2s_conv_bias_act(const float *x, const float *w, const float *bias, float *
                       int Cout, int H, int W, int k, int mode, int act, float alpha, float gain,
                       g2s_stream_t stream);
 
+/* g2s_modconv and g2s_conv_bias_act behind one entry point (in_scale / out_scale / bias may each be
+ * NULL, act as above), plus y_is_zero: the caller's promise that y is already all zeros — e.g. a slice
+ * of a pool cleared ONCE per training step (gan-2d-to-3d_amd/zeropool.py).  Launches that add partial
+ * sums into y (split-K slices of small layers; polyphase classes that leave holes) then skip their own
+ * clear: one graph node less each (36 of step 1's 319 nodes were such clears).
+ * g2s_modconv_needs_zero answers, without launching anything, whether that signature adds into a
+ * cleared output (1) or overwrites y (0) under the calling thread's current tuning state, so that
+ * only those outputs are taken from the pool.  fused = a bias / activation epilogue is present. */
+int g2s_modconv_ex(const float *x, const float *w, const float *in_scale, const float *out_scale,
+                   const float *bias, float *y, int B, int Cin, int Cout, int H, int W, int k, int mode,
+                   int transpose, int act, float alpha, float gain, int y_is_zero, g2s_stream_t stream);
+int g2s_modconv_needs_zero(int B, int Cin, int Cout, int H, int W, int k, int mode, int transpose,
+                           int has_scales, int fused);
+
 /* General 2-D convolution on the same fp32-MFMA implicit-GEMM kernel: the trained nets of the step
  * (depth / albedo / viewpoint / lighting / offset-encoder nets, GAN2Shape/networks.py:23-244:
  * nn.Conv2d k in {1,3,4,5} stride 1/2, nn.ConvTranspose2d k4 stride 1/2), forward and data-gradient.

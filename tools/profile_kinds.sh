@@ -9,6 +9,6 @@ cd /tmp
 for K in ${1:-1 2 3}; do
   rocprofv3 --kernel-trace -d /tmp/prof_k$K -o k$K --output-format csv -- python3 $R/bench.py --only $K --steps 20 --warmup 10 --no-cpu-baseline > $R/gpurun_out/kinds/bench_k$K.json 2> $R/gpurun_out/kinds/bench_k$K.err
   F=$(find /tmp/prof_k$K -name "*kernel_trace.csv" | head -1)
-  python3 $R/tools/window_trace.py $F 20 45 > $R/gpurun_out/kinds/step$K.txt
+  python3 $R/tools/window_trace.py $F 20 250 > $R/gpurun_out/kinds/step$K.txt
   echo "step $K done"
 done
