@@ -432,11 +432,45 @@ __global__ __launch_bounds__(NTHREADS) void conv_bwd_kernel(ConvDesc d, WgradPar
 // per K tile; latencies overlap across the 2-3 workgroups a CU holds (LDS 37 KB, < 170 registers).
 // LDS images are [row][k] with k contiguous (4 halves = one MFMA operand = one ds_read_b64).
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int T> struct KTile16 {       // channels per K tile such that K = CPT * T is a multiple of 8
     static constexpr int CPT = (T == 9) ? 8 : (T == 4) ? 8 : (T == 2) ? 16 : 32;
     static constexpr int KT = CPT * T;  // 72, 32, 32, 32
 };
+
+
+// Epilogue of the fp16-operand bodies (as the fp32 kernel): C[m][n], m = (r&3) + 8*(r>>2) + 4*(lane>>5), n = lane&31.
+template <int BM, int BN>
+__device__ __forceinline__ void f16_epilogue(const ConvDesc &d, const ConvClass &c, f32x16 (&acc)[BM / 64][BN / 64],
+                                             const int m0, const int n0, const int wm, const int wn, const int l31,
+                                             const int lk, const int Ncls) {
+    constexpr int WMT = BM / 64, WNT = BN / 64;
+#pragma unroll
+    for (int j = 0; j < WNT; j++) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+        if (n >= Ncls) continue;
+        const int b = n / (c.OH * c.OW);
+        const int r_ = n % (c.OH * c.OW);
+        const int oy = (r_ / c.OW) * d.os + c.oy0, ox = (r_ % c.OW) * d.os + c.ox0;
+        float *yb = d.y + ((size_t)b * d.M * d.OHf + oy) * d.OWf + ox;
+        const float *ob = d.out_scale ? d.out_scale + (size_t)b * d.M : nullptr;
+#pragma unroll
+        for (int i = 0; i < WMT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= d.M) continue;
+                float v = acc[i][j][r];
+                if (ob) v *= ob[m];
+                if (d.bias) v += d.bias[m];
+                if (d.act) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
+                float *dst = yb + (size_t)m * d.OHf * d.OWf;
+                if (d.splitk > 1) unsafeAtomicAdd(dst, v);
+                else *dst = v;
+            }
+    }
+}
 
 template <int BM, int BN, int T, bool SCALE>
 __device__ __forceinline__ void modconv_f16_body(const ConvDesc &d, const ConvClass &c, _Float16 *As, _Float16 *Bs,
@@ -594,39 +628,389 @@ __device__ __forceinline__ void modconv_f16_body(const ConvDesc &d, const ConvCl
     }
 }
 
+
+// ---- fp16 operands, the 4- / 2- / 1-tap polyphase classes and 1x1 kernels: the generic gather of
+// modconv_f16_body (4 consecutive k per group, dword loads) in the pipelined schedule of the 3x3 form
+// below — K tile of 32, LDS double-buffered, tile t+1 converted and written and tile t+2 requested
+// behind tile t's two v_mfma_f32_32x32x16_f16 steps, one raw barrier per K tile.
+template <int BM, int BN, int T, bool SCALE>
+__device__ __forceinline__ void modconv_f16p_body(const ConvDesc &d, const ConvClass &c, _Float16 *smem,
+                                                  const int (&stab)[25], const int tile_id) {
+    static_assert(T == 4 || T == 2 || T == 1, "polyphase classes / 1x1 kernels");
+    constexpr int CPT = KTile16<T>::CPT, KT = KTile16<T>::KT, KTP = KT + 8;   // 32 k per tile, pitch 40 halves
+    static_assert(KT == 32, "two K = 16 steps per tile");
+    constexpr int WMT = BM / 64, WNT = BN / 64;
+    constexpr int GA = BM * (KT / 4) / NTHREADS, GB = BN * (KT / 4) / NTHREADS;
+    static_assert(GA * NTHREADS == BM * (KT / 4) && GB * NTHREADS == BN * (KT / 4), "whole groups per thread");
+    constexpr int BUF = (BM + BN) * KTP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lk = lane >> 5;
+    const int Ncls = d.B * c.OH * c.OW;
+    const int tiles_m = (d.M + BM - 1) / BM;
+    const int m0 = (tile_id % tiles_m) * BM;
+    const int n0 = (tile_id / tiles_m) * BN;
+    const int ktiles = (d.Cr + CPT - 1) / CPT;
+    const int per = (ktiles + d.splitk - 1) / d.splitk;
+    const int kt_begin = blockIdx.y * per;
+    const int kt_end = min(ktiles, kt_begin + per);
+    const int HW = d.H * d.W;
+    constexpr int OOB = 0x7fffffff;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, d.B * d.Cr * HW * 4, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)d.w, 0, d.w_bytes, 0x00020000);
+    const auto rsc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(SCALE ? d.in_scale : d.w), 0, SCALE ? d.B * d.Cr * 4 : 4, 0x00020000);
+    const int nB = tid % BN;
+    const int ng = n0 + nB;
+    const bool n_ok = ng < Ncls;
+    int bb = 0, iy0 = 0, ix0 = 0;
+    if (n_ok) {
+        bb = ng / (c.OH * c.OW);
+        const int r = ng % (c.OH * c.OW);
+        iy0 = (r / c.OW) * d.is;
+        ix0 = (r % c.OW) * d.is;
+    }
+    int offB[GB][4], offS[GB][4], offA[GA][4];
+    unsigned dchB[GB], dchA[GA];    // 4 x 8 bits: channel-in-tile of each element (partial last tile)
+#pragma unroll
+    for (int e = 0; e < GB; e++) {
+        const int kq = (tid + e * NTHREADS) / BN;
+        dchB[e] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = kq * 4 + j;
+            const int dch = k / T, t = k - dch * T;
+            const int tb = stab[t];
+            const int iy = iy0 + (tb & 0xff) - 8, ix = ix0 + ((tb >> 8) & 0xff) - 8;
+            const bool ok = n_ok & (iy >= 0) & (iy < d.H) & (ix >= 0) & (ix < d.W);
+            offB[e][j] = ok ? (((bb * d.Cr + dch) * d.H + iy) * d.W + ix) * 4 : OOB;
+            offS[e][j] = (SCALE && n_ok) ? (bb * d.Cr + dch) * 4 : OOB;
+            dchB[e] |= (unsigned)dch << (8 * j);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < GA; e++) {
+        const int gidx = tid + e * NTHREADS;
+        const int kq = gidx % (KT / 4), m = gidx / (KT / 4);
+        const bool ok = m0 + m < d.M;
+        dchA[e] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = kq * 4 + j;
+            const int dch = k / T, t = k - dch * T;
+            offA[e][j] = ok ? ((m0 + m) * d.w_ms + dch * d.w_ks + (stab[t] >> 16)) * 4 : OOB;
+            dchA[e] |= (unsigned)dch << (8 * j);
+        }
+    }
+    float ra[GA][4], rb[GB][4], rsv[SCALE ? GB : 1][4];
+    auto load_tile = [&](int kt) {
+        const int ch0 = kt * CPT, have = d.Cr - ch0;
+#pragma unroll
+        for (int e = 0; e < GA; e++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool out = (int)((dchA[e] >> (8 * j)) & 0xff) >= have;
+                ra[e][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, out ? OOB : offA[e][j], ch0 * d.w_ks * 4, 0));
+            }
+#pragma unroll
+        for (int e = 0; e < GB; e++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool out = (int)((dchB[e] >> (8 * j)) & 0xff) >= have;
+                rb[e][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, out ? OOB : offB[e][j], ch0 * HW * 4, 0));
+                if constexpr (SCALE)
+                    rsv[e][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, out ? OOB : offS[e][j], ch0 * 4, 0));
+            }
+    };
+    auto store_tile = [&](_Float16 *abuf, _Float16 *bbuf) {
+#pragma unroll
+        for (int e = 0; e < GA; e++) {
+            const int gidx = tid + e * NTHREADS;
+            f16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; j++) h[j] = (_Float16)ra[e][j];
+            *reinterpret_cast<f16x4 *>(&abuf[(gidx / (KT / 4)) * KTP + (gidx % (KT / 4)) * 4]) = h;
+        }
+#pragma unroll
+        for (int e = 0; e < GB; e++) {
+            f16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; j++) h[j] = (_Float16)(SCALE ? rb[e][j] * rsv[SCALE ? e : 0][j] : rb[e][j]);
+            *reinterpret_cast<f16x4 *>(&bbuf[nB * KTP + ((tid + e * NTHREADS) / BN) * 4]) = h;
+        }
+    };
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; i++)
+#pragma unroll
+        for (int j = 0; j < WNT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    load_tile(kt_begin);
+    store_tile(smem, smem + BM * KTP);
+    if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; kt++) {
+        const int cur = (kt - kt_begin) & 1;
+        const _Float16 *As = smem + cur * BUF, *Bs = As + BM * KTP;
+#pragma unroll
+        for (int ks = 0; ks < KT / 16; ks++) {
+            f16x8 a[WMT], b[WNT];
+#pragma unroll
+            for (int i = 0; i < WMT; i++)
+                a[i] = *reinterpret_cast<const f16x8 *>(&As[(wm * (BM / 2) + i * 32 + l31) * KTP + ks * 16 + lk * 8]);
+#pragma unroll
+            for (int j = 0; j < WNT; j++)
+                b[j] = *reinterpret_cast<const f16x8 *>(&Bs[(wn * (BN / 2) + j * 32 + l31) * KTP + ks * 16 + lk * 8]);
+#pragma unroll
+            for (int i = 0; i < WMT; i++)
+#pragma unroll
+                for (int j = 0; j < WNT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < kt_end) {
+            _Float16 *an = smem + (cur ^ 1) * BUF;
+            store_tile(an, an + BM * KTP);
+            if (kt + 2 < kt_end) load_tile(kt + 2);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    f16_epilogue<BM, BN>(d, c, acc, m0, n0, wm, wn, l31, lk, Ncls);
+}
+
+// ---- fp16 operands, 3x3 classes (T = 9) on maps at least 4 wide: the pipelined form.
+// K is re-ordered into QUADS: (channel, kernel row) -> 4 k-slots = the row's 3 taps + one zero, so that
+// every operand element group is ONE dwordx3 buffer load (weights: the 3 contiguous taps of a kernel
+// row; activations: 3 horizontally adjacent pixels — at the left / right image border the load is
+// shifted inwards by one pixel and the triple re-aligned in registers) and ONE ds_write_b64 of 4
+// halves: 12 + 12 wide loads per thread and K tile of 4 channels instead of 72 + 72 dword loads for 8.
+// The 25 % zero slots cost matrix time only, and v_mfma_f32_32x32x16_f16 (gfx950: K = 16 in 32 cycles)
+// is 12x ahead of the fp32 MFMA per channel: this kernel is paced by its operand traffic (L1 / LDS),
+// so the schedule is the fp32 kernel's — LDS double-buffered, tile t+1 converted and written and tile
+// t+2 requested in the shadow of tile t's MFMAs, one raw barrier per K tile (no vmcnt drain).
+template <int BM, int BN, bool SCALE>
+__device__ __forceinline__ void modconv_f16w_body(const ConvDesc &d, const ConvClass &c, _Float16 *smem,
+                                                  const int (&stab)[25], const int tile_id) {
+    constexpr int CPT = 4, QT = CPT * 3, KT = QT * 4, KTP = KT + 8;   // 12 quads = 48 k-slots, pitch 56 halves
+    constexpr int WMT = BM / 64, WNT = BN / 64;
+    constexpr int GA = (BM * QT + NTHREADS - 1) / NTHREADS;
+    constexpr int GB = (BN * QT + NTHREADS - 1) / NTHREADS;
+    static_assert((BM * QT) % NTHREADS == 0 && (BN * QT) % NTHREADS == 0, "whole groups per thread");
+    constexpr int BUF = (BM + BN) * KTP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lk = lane >> 5;
+    const int Ncls = d.B * c.OH * c.OW;
+    const int tiles_m = (d.M + BM - 1) / BM;
+    const int m0 = (tile_id % tiles_m) * BM;
+    const int n0 = (tile_id / tiles_m) * BN;
+    const int ktiles = (d.Cr + CPT - 1) / CPT;
+    const int per = (ktiles + d.splitk - 1) / d.splitk;
+    const int kt_begin = blockIdx.y * per;
+    const int kt_end = min(ktiles, kt_begin + per);
+    const int HW = d.H * d.W;
+    constexpr int OOB = 0x7fffffff;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, d.B * d.Cr * HW * 4, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void *)d.w, 0, d.w_bytes, 0x00020000);
+    const auto rsc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(SCALE ? d.in_scale : d.w), 0, SCALE ? d.B * d.Cr * 4 : 4, 0x00020000);
+
+    // ---- this thread's pixel column (the same for all its activation quads)
+    const int nB = tid % BN;
+    const int ng = n0 + nB;
+    const bool n_ok = ng < Ncls;
+    int bb = 0, iy0 = 0, ix0 = 0;
+    if (n_ok) {
+        bb = ng / (c.OH * c.OW);
+        const int r = ng % (c.OH * c.OW);
+        iy0 = (r / c.OW) * d.is;
+        ix0 = (r % c.OW) * d.is;
+    }
+    // taps 3ky .. 3ky+2 of a kernel row share dy and step through x by +1 (gather) or -1 (the adjoint
+    // of a stride-1 convolution): one triple starting at the smaller x, reversed in registers if needed
+    const int dxa = ((stab[0] >> 8) & 0xff) - 8, dxb = ((stab[2] >> 8) & 0xff) - 8;
+    const bool rev = dxa > dxb;
+    const int ixmin = ix0 + (rev ? dxb : dxa);
+    const int xa = min(max(ixmin, 0), d.W - 3);         // the triple is loaded from [xa, xa + 2]
+    const bool left = ixmin < xa, right = ixmin > xa;  // shifted by one pixel at the image border
+    int offB[GB];
+    int dchB[GB];
+#pragma unroll
+    for (int e = 0; e < GB; e++) {
+        const int q = (tid + e * NTHREADS) / BN;
+        const int dch = q / 3, ky = q - dch * 3;
+        const int iy = iy0 + (stab[3 * ky] & 0xff) - 8;
+        const bool ok = n_ok && iy >= 0 && iy < d.H;
+        offB[e] = ok ? (((bb * d.Cr + dch) * d.H + iy) * d.W + xa) * 4 : OOB;
+        dchB[e] = dch;
+    }
+    const int offS = (SCALE && n_ok) ? bb * d.Cr * 4 : OOB;
+    // ---- weight quads: lanes along the 12 quads of one output channel (144 contiguous bytes forward)
+    int offA[GA], ldsA[GA], dchA[GA];
+#pragma unroll
+    for (int e = 0; e < GA; e++) {
+        const int idx = tid + e * NTHREADS;
+        const int m = idx / QT, q = idx - m * QT;
+        const int dch = q / 3, ky = q - dch * 3;
+        offA[e] = (m0 + m < d.M) ? ((m0 + m) * d.w_ms + dch * d.w_ks + 3 * ky) * 4 : OOB;
+        ldsA[e] = m * KTP + q * 4;
+        dchA[e] = dch;
+    }
+
+    u32x3 ra[GA], rb[GB];
+    float rs[CPT];
+    auto load_tile = [&](int kt) {
+        const int ch0 = kt * CPT, have = d.Cr - ch0;     // channels present in this tile (partial last tile)
+#pragma unroll
+        for (int e = 0; e < GA; e++)
+            ra[e] = __builtin_amdgcn_raw_buffer_load_b96(rw, dchA[e] >= have ? OOB : offA[e], ch0 * d.w_ks * 4, 0);
+#pragma unroll
+        for (int e = 0; e < GB; e++)
+            rb[e] = __builtin_amdgcn_raw_buffer_load_b96(rx, dchB[e] >= have ? OOB : offB[e], ch0 * HW * 4, 0);
+        if constexpr (SCALE) {
+#pragma unroll
+            for (int cc = 0; cc < CPT; cc++)
+                rs[cc] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, cc >= have ? OOB : offS + 4 * cc, ch0 * 4, 0));
+        }
+    };
+    auto store_tile = [&](_Float16 *abuf, _Float16 *bbuf) {
+#pragma unroll
+        for (int e = 0; e < GA; e++) {
+            f16x4 h;
+            h[0] = (_Float16)__uint_as_float(ra[e].x);
+            h[1] = (_Float16)__uint_as_float(ra[e].y);
+            h[2] = (_Float16)__uint_as_float(ra[e].z);
+            h[3] = (_Float16)0.0f;
+            *reinterpret_cast<f16x4 *>(&abuf[ldsA[e]]) = h;
+        }
+#pragma unroll
+        for (int e = 0; e < GB; e++) {
+            const float l0 = __uint_as_float(rb[e].x), l1 = __uint_as_float(rb[e].y), l2 = __uint_as_float(rb[e].z);
+            float e0 = left ? 0.0f : (right ? l1 : l0);
+            float e1 = left ? l0 : (right ? l2 : l1);
+            float e2 = left ? l1 : (right ? 0.0f : l2);
+            if constexpr (SCALE) {
+                const float sc = dchB[e] == 0 ? rs[0] : dchB[e] == 1 ? rs[1] : dchB[e] == 2 ? rs[2] : rs[3];
+                e0 *= sc;
+                e1 *= sc;
+                e2 *= sc;
+            }
+            f16x4 h;
+            h[0] = (_Float16)(rev ? e2 : e0);
+            h[1] = (_Float16)e1;
+            h[2] = (_Float16)(rev ? e0 : e2);
+            h[3] = (_Float16)0.0f;
+            const int q = (tid + e * NTHREADS) / BN;
+            *reinterpret_cast<f16x4 *>(&bbuf[nB * KTP + q * 4]) = h;
+        }
+    };
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; i++)
+#pragma unroll
+        for (int j = 0; j < WNT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    load_tile(kt_begin);
+    store_tile(smem, smem + BM * KTP);
+    if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; kt++) {
+        const int cur = (kt - kt_begin) & 1;
+        const _Float16 *As = smem + cur * BUF, *Bs = As + BM * KTP;
+#pragma unroll
+        for (int ks = 0; ks < KT / 16; ks++) {
+            f16x8 a[WMT], b[WNT];
+#pragma unroll
+            for (int i = 0; i < WMT; i++)
+                a[i] = *reinterpret_cast<const f16x8 *>(&As[(wm * (BM / 2) + i * 32 + l31) * KTP + ks * 16 + lk * 8]);
+#pragma unroll
+            for (int j = 0; j < WNT; j++)
+                b[j] = *reinterpret_cast<const f16x8 *>(&Bs[(wn * (BN / 2) + j * 32 + l31) * KTP + ks * 16 + lk * 8]);
+#pragma unroll
+            for (int i = 0; i < WMT; i++)
+#pragma unroll
+                for (int j = 0; j < WNT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < kt_end) {
+            _Float16 *an = smem + (cur ^ 1) * BUF;
+            store_tile(an, an + BM * KTP);                 // tile kt+1 (requested one iteration ago)
+            if (kt + 2 < kt_end) load_tile(kt + 2);
+        }
+        // LDS hand-over only (no vmcnt drain: the loads of tile kt+2 stay in flight over the barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- epilogue (as the fp32 kernel): C[m][n], m = (r&3) + 8*(r>>2) + 4*(lane>>5), n = lane&31
+#pragma unroll
+    for (int j = 0; j < WNT; j++) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+        if (n >= Ncls) continue;
+        const int b = n / (c.OH * c.OW);
+        const int r_ = n % (c.OH * c.OW);
+        const int oy = (r_ / c.OW) * d.os + c.oy0, ox = (r_ % c.OW) * d.os + c.ox0;
+        float *yb = d.y + ((size_t)b * d.M * d.OHf + oy) * d.OWf + ox;
+        const float *ob = d.out_scale ? d.out_scale + (size_t)b * d.M : nullptr;
+#pragma unroll
+        for (int i = 0; i < WMT; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m >= d.M) continue;
+                float v = acc[i][j][r];
+                if (ob) v *= ob[m];
+                if (d.bias) v += d.bias[m];
+                if (d.act) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
+                float *dst = yb + (size_t)m * d.OHf * d.OWf;
+                if (d.splitk > 1) unsafeAtomicAdd(dst, v);
+                else *dst = v;
+            }
+    }
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(NTHREADS) void modconv_f16_kernel(ConvDesc d) {
     constexpr int KTP = 72 + 4;
-    __shared__ __attribute__((aligned(16))) _Float16 As[BM * KTP];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[BN * KTP];
+    // one buffer for both forms: 2 x (BM + BN) rows of 56 halves (pipelined 3x3 form) >= (BM + BN) rows of 76
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (BM + BN) * 56];
+    _Float16 *As = smem, *Bs = smem + BM * KTP;
     __shared__ int stab[25];
     const ConvClass &c = d.cls[blockIdx.z];
     const int tiles_m = (d.M + BM - 1) / BM;
     const int tile_id = xcd_logical_tile();
     if ((int)(tile_id / tiles_m) * BN >= d.B * c.OH * c.OW) return;
-    const int cpt = c.T == 9 ? 8 : c.T == 4 ? 8 : c.T == 2 ? 16 : 32;
+    const bool wide = c.T == 9 && d.W >= 4;   // the pipelined quad form (4 channels per K tile)
+    const int cpt = wide ? 4 : c.T == 9 ? 8 : c.T == 4 ? 8 : c.T == 2 ? 16 : 32;
     const int ktiles = (d.Cr + cpt - 1) / cpt;
     const int per = (ktiles + d.splitk - 1) / d.splitk;
     if ((int)blockIdx.y * per >= ktiles) return;
     if (threadIdx.x < 25) stab[threadIdx.x] = c.tab[threadIdx.x];
     __syncthreads();
     const bool scale = d.in_scale != nullptr;
+    if (wide) {
+        if (scale) modconv_f16w_body<BM, BN, true>(d, c, smem, stab, tile_id);
+        else modconv_f16w_body<BM, BN, false>(d, c, smem, stab, tile_id);
+        return;
+    }
     switch (c.T) {
     case 9:
         if (scale) modconv_f16_body<BM, BN, 9, true>(d, c, As, Bs, stab, tile_id);
         else modconv_f16_body<BM, BN, 9, false>(d, c, As, Bs, stab, tile_id);
         break;
     case 4:
-        if (scale) modconv_f16_body<BM, BN, 4, true>(d, c, As, Bs, stab, tile_id);
-        else modconv_f16_body<BM, BN, 4, false>(d, c, As, Bs, stab, tile_id);
+        if (scale) modconv_f16p_body<BM, BN, 4, true>(d, c, smem, stab, tile_id);
+        else modconv_f16p_body<BM, BN, 4, false>(d, c, smem, stab, tile_id);
         break;
     case 2:
-        if (scale) modconv_f16_body<BM, BN, 2, true>(d, c, As, Bs, stab, tile_id);
-        else modconv_f16_body<BM, BN, 2, false>(d, c, As, Bs, stab, tile_id);
+        if (scale) modconv_f16p_body<BM, BN, 2, true>(d, c, smem, stab, tile_id);
+        else modconv_f16p_body<BM, BN, 2, false>(d, c, smem, stab, tile_id);
         break;
     default:
-        if (scale) modconv_f16_body<BM, BN, 1, true>(d, c, As, Bs, stab, tile_id);
-        else modconv_f16_body<BM, BN, 1, false>(d, c, As, Bs, stab, tile_id);
+        if (scale) modconv_f16p_body<BM, BN, 1, true>(d, c, smem, stab, tile_id);
+        else modconv_f16p_body<BM, BN, 1, false>(d, c, smem, stab, tile_id);
         break;
     }
 }
@@ -782,6 +1166,7 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
         if (d.M > cfgs[i][0] / 2 && blocks >= 512) { pick = i; break; }
     }
     if (d.M <= 32 && nmax >= 1024 && !f16_operands) pick = 3;   // a 64-row tile would be half padding
+    if (f16_operands && pick == 1) pick = 2;   // fp16 form: 128x128 or 64x64 only; fewer than 512 big tiles -> small ones
     if (tuned_tile >= 0 && g_force_tile != -2) pick = tuned_tile;
     else tuned_splitk = -1;
     if (g_force_tile >= 0) pick = g_force_tile;

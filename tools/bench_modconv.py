@@ -1,5 +1,5 @@
 """Per-layer timing of g2s_modconv on the StyleGAN2-128 generator shapes (B = 8), forward and
-data-gradient.  python tools/bench_modconv.py"""
+data-gradient.  python tools/bench_modconv.py [B] [f16|f32] [direct]"""
 import os
 import sys
 
@@ -31,6 +31,12 @@ def timeit(fn, n=10):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    from gan2shape_amd import modconv as mc
+    if "f16" in sys.argv[2:]:
+        mc.OPERANDS = "f16"       # fp16 MFMA operands (BASELINE config 5)
+    if "direct" in sys.argv[2:]:
+        mc.WINOGRAD = False       # the direct implicit-GEMM kernel everywhere
+    print(f"B = {B}, operands {mc.OPERANDS}, winograd {mc.WINOGRAD}")
     tot_t = tot_f = 0
     for name, cin, cout, h, k, mode in LAYERS:
         x = torch.randn(B, cin, h, h, device="cuda")
