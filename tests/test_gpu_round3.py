@@ -1,0 +1,117 @@
+"""-m gpu: round-3 additions of the C ABI — reproducible launch partitions (g2s_set_deterministic),
+the step-wide cleared pool (g2s_modconv_ex / g2s_modconv_needs_zero, zeropool.py) — against the
+oracle and against the default launch mode."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import capi  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def L():
+    import gan2shape_amd  # noqa: F401
+    from gan2shape_amd import lib
+    return lib.load()
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+# Small layers: few tiles -> the default mode splits K and adds partial sums with float atomics.
+SMALL = [(1, 512, 512, 16, 3, 0), (8, 512, 512, 4, 3, 0), (8, 512, 512, 8, 3, 1), (1, 256, 512, 16, 3, 0)]
+
+
+@pytest.mark.parametrize("B,cin,cout,H,k,mode", SMALL)
+def test_deterministic_mode_repeats_bitwise_and_matches_oracle(L, B, cin, cout, H, k, mode):
+    """g2s_set_deterministic(1): split-K 1 in the direct kernel, Winograd partial sums only as stored
+    slices -> the same bits on every run; the values equal the oracle's (and the default mode's)
+    within the fp32 summation-order tolerance of tests/test_gpu_conv_tiles.py."""
+    from gan2shape_amd import lib
+    from gan2shape_amd import modconv as mc
+    rng = np.random.default_rng(B + cin + H + mode)
+    w = (rng.standard_normal((cout, cin, k, k)) / math.sqrt(cin * k * k)).astype(np.float32)
+    x = rng.standard_normal((B, cin, H, H)).astype(np.float32)
+    s = (1 + 0.3 * rng.standard_normal((B, cin))).astype(np.float32)
+    exp = capi.modconv(x, w, s, 1.0, False, mode)
+    xd, wd, sd = dev(x), dev(w), dev(s)
+    assert L.g2s_modconv_needs_zero(B, cin, cout, H, H, k, mode, 0, 1, 0) == 1   # default mode: adds into y
+    prev = lib.set_deterministic(True)
+    try:
+        assert L.g2s_get_deterministic() == 1
+        if mode == 0:   # a polyphase scatter leaves holes whatever the split
+            assert L.g2s_modconv_needs_zero(B, cin, cout, H, H, k, mode, 0, 1, 0) == 0
+        saved = mc.WINO_FORCE
+        runs = []
+        for force in ("direct", saved):
+            mc.WINO_FORCE = force
+            ys = [mc.modconv_raw(xd, wd, sd, None, mode, 0).clone() for _ in range(4)]
+            assert all(torch.equal(ys[0], y) for y in ys[1:]), f"run-to-run differences ({force})"
+            runs.append(ys[0])
+        mc.WINO_FORCE = saved
+    finally:
+        lib.set_deterministic(prev)
+    assert L.g2s_get_deterministic() == int(prev)
+    y_default = mc.modconv_raw(xd, wd, sd, None, mode, 0)
+    tol = 2e-5 * max(1.0, math.sqrt(cin * k * k / 1152))
+    for y in runs + [y_default]:
+        np.testing.assert_allclose(y.cpu().numpy(), exp, rtol=2e-4, atol=tol * max(1.0, float(np.abs(exp).max())))
+
+
+def test_deterministic_weight_gradient_repeats_bitwise(L):
+    """The weight-gradient GEMM without its pixel split: one workgroup owns every dw element."""
+    from gan2shape_amd import lib
+    from gan2shape_amd.op import conv as gconv
+    torch.manual_seed(0)
+    A = torch.randn(9, 64, 32, 32, device="cuda")
+    G = torch.randn(9, 128, 16, 16, device="cuda")
+    ref = torch.nn.grad.conv2d_weight(A.double().cpu(), (128, 64, 4, 4), G.double().cpu(), stride=2, padding=1)
+    prev = lib.set_deterministic(True)
+    try:
+        dws = [gconv._wgrad(G, A, 4, 2, 1).clone() for _ in range(3)]
+    finally:
+        lib.set_deterministic(prev)
+    assert torch.equal(dws[0], dws[1]) and torch.equal(dws[0], dws[2])
+    dflt = gconv._wgrad(G, A, 4, 2, 1)
+    for dw in (dws[0], dflt):
+        assert float((dw.double().cpu() - ref).norm()) <= 2e-5 * float(ref.norm())
+
+
+def test_zero_pool_hands_out_cleared_slices_and_results_do_not_change(L):
+    """zeropool: the second step of a kind gets a pool as large as the first one asked for; launches
+    that add partial sums take their output from it (no clear of their own) and produce what the
+    library's own clear produces."""
+    from gan2shape_amd import modconv as mc
+    from gan2shape_amd import zeropool
+    torch.manual_seed(0)
+    x = torch.randn(1, 512, 16, 16, device="cuda")
+    w = torch.randn(512, 512, 3, 3, device="cuda") / 68
+    b = torch.randn(512, device="cuda")
+    saved = mc.WINO_FORCE
+    mc.WINO_FORCE = "direct"
+    try:
+        zeropool.end()
+        y0 = mc.conv_bias_relu(x, w, b)               # no step active: the library clears y itself
+        zeropool.begin("test", x.device)              # first step of this kind: nothing to hand out yet
+        assert zeropool.take((4,), x.device) is None
+        y1 = mc.conv_bias_relu(x, w, b)
+        zeropool.begin("test", x.device)              # second step: pool sized by the first
+        y2 = mc.conv_bias_relu(x, w, b)
+        pool = zeropool._state["buf"]
+        assert pool is not None and pool.numel() >= y2.numel()
+        assert y2.data_ptr() >= pool.data_ptr() and y2.data_ptr() < pool.data_ptr() + pool.numel() * 4
+        extra = zeropool.take((4,), x.device)
+        assert extra is None or float(extra.abs().max()) == 0.0
+    finally:
+        mc.WINO_FORCE = saved
+        zeropool.end()
+    ref = torch.relu(torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1))
+    for y in (y0, y1, y2):
+        assert float((y.double().cpu() - ref).norm()) <= 2e-5 * float(ref.norm())
+    # a large layer overwrites its output: never taken from the pool
+    assert L.g2s_modconv_needs_zero(8, 128, 128, 128, 128, 3, 0, 0, 0, 0) == 0
