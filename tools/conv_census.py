@@ -45,6 +45,9 @@ wrap("g2s_modconv", lambda a: (a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12]
 # g2s_conv_bias_act(x,w,bias,y,B,Cin,Cout,H,W,k,mode,act,alpha,gain,stream)
 wrap("g2s_conv_bias_act", lambda a: (a[4], a[5], a[6], a[7], a[8], a[9], a[10], 0, False, False))
 
+# g2s_modconv_ex(x,w,in_scale,out_scale,bias,y,B,Cin,Cout,H,W,k,mode,transpose,act,alpha,gain,y_is_zero,stream)
+wrap("g2s_modconv_ex", lambda a: (a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[2] is not None, a[3] is not None))
+
 # g2s_conv3x3_wino(x,U,in_scale,out_scale,bias,y,B,Cr,M,H,W,act,alpha,gain,splitk,ws,ws_floats,stream)
 wrap("g2s_conv3x3_wino", lambda a: (a[6], a[7], a[8], a[9], a[10], 3, 0, 0, a[2] is not None, a[3] is not None))
 
