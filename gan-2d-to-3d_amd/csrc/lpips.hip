@@ -64,11 +64,15 @@ __global__ __launch_bounds__(64 * SL) void lpips_layer_fwd(const float *__restri
 }
 
 // g0[n,c,p] = gout[n]/HW * ( 2 w_c diff_c / a  -  f0_c / (a^2 n0) * sum_k 2 w_k diff_k f0_k )
+// g_in (optional): a gradient that reaches f0 from elsewhere (the next VGG slice, through its max pool),
+// added here; gate: f0 is a ReLU output — the sum passes only where f0 > 0 (the ReLU's own backward),
+// so that the trunk's backward needs neither an add nor a gate launch at a tap.
 template <int SL>
 __global__ __launch_bounds__(64 * SL) void lpips_layer_bwd(const float *__restrict__ f0,
                                                            const float *__restrict__ f1,
                                                            const float *__restrict__ w,
                                                            const float *__restrict__ gout,
+                                                           const float *__restrict__ g_in, const int gate,
                                                            float *__restrict__ g0, int C, int HW) {
     __shared__ float red[SL][64];
     const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -97,10 +101,14 @@ __global__ __launch_bounds__(64 * SL) void lpips_layer_bwd(const float *__restri
     const float go = gout[n] / (float)HW;
     const float k2 = (n0 > 0.0f) ? t * ia * ia / n0 : 0.0f;
     if (!ok) return;
+    const float *gi = g_in ? g_in + (size_t)n * C * HW + p : nullptr;
 #pragma unroll 4
     for (int c = sl; c < C; c += SL) {
         const float x = a[(size_t)c * HW];
-        g[(size_t)c * HW] = go * (2.0f * w[c] * (x * ia - b[(size_t)c * HW] * ib) * ia - x * k2);
+        float v = go * (2.0f * w[c] * (x * ia - b[(size_t)c * HW] * ib) * ia - x * k2);
+        if (gi) v += gi[(size_t)c * HW];
+        if (gate && !(x > 0.0f)) v = 0.0f;
+        g[(size_t)c * HW] = v;
     }
 }
 
@@ -117,12 +125,20 @@ extern "C" int g2s_lpips_layer_fwd(const float *f0, const float *f1, const float
     return check_launch("g2s_lpips_layer_fwd");
 }
 
+extern "C" int g2s_lpips_layer_bwd_ex(const float *f0, const float *f1, const float *w, const float *gout,
+                                      const float *g_in, int relu_gate, float *g0, int N, int C, int HW,
+                                      g2s_stream_t stream) {
+    G2S_REQUIRE(f0 && f1 && w && gout && g0 && N > 0 && C > 0 && HW > 0, "bad argument");
+    G2S_REQUIRE(N <= 65535, "N too large for grid.y");
+    if (HW <= 1024)
+        lpips_layer_bwd<16><<<dim3(cdiv(HW, 64), N), 1024, 0, as_stream(stream)>>>(f0, f1, w, gout, g_in, relu_gate, g0, C, HW);
+    else
+        lpips_layer_bwd<4><<<dim3(cdiv(HW, 64), N), 256, 0, as_stream(stream)>>>(f0, f1, w, gout, g_in, relu_gate, g0, C, HW);
+    return check_launch("g2s_lpips_layer_bwd");
+}
+
 extern "C" int g2s_lpips_layer_bwd(const float *f0, const float *f1, const float *w,
                                    const float *gout, float *g0, int N, int C, int HW,
                                    g2s_stream_t stream) {
-    G2S_REQUIRE(f0 && f1 && w && gout && g0 && N > 0 && C > 0 && HW > 0, "bad argument");
-    G2S_REQUIRE(N <= 65535, "N too large for grid.y");
-    if (HW <= 1024) lpips_layer_bwd<16><<<dim3(cdiv(HW, 64), N), 1024, 0, as_stream(stream)>>>(f0, f1, w, gout, g0, C, HW);
-    else lpips_layer_bwd<4><<<dim3(cdiv(HW, 64), N), 256, 0, as_stream(stream)>>>(f0, f1, w, gout, g0, C, HW);
-    return check_launch("g2s_lpips_layer_bwd");
+    return g2s_lpips_layer_bwd_ex(f0, f1, w, gout, nullptr, 0, g0, N, C, HW, stream);
 }

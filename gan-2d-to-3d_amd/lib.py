@@ -52,6 +52,7 @@ SIGNATURES = {
     "g2s_demod_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_lpips_layer_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_lpips_layer_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "g2s_lpips_layer_bwd_ex": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
     "g2s_weighted_l1_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_weighted_l1_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_view_transform_fwd": (_i, [_p, _f, _f, _f, _p, _p, _i, _p]),

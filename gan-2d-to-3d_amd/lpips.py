@@ -84,6 +84,94 @@ class _MaxPool2x2(Function):
         return gx
 
 
+def _pool_ok(mod):
+    return (mod.kernel_size in (2, (2, 2)) and mod.stride in (2, (2, 2)) and mod.padding in (0, (0, 0))
+            and not mod.ceil_mode and mod.dilation in (1, (1, 1)))
+
+
+class _VggLpips(Function):
+    """The whole metric as ONE autograd node (frozen VGG16 + lin layers, gradient-free target):
+
+    forward   prediction and target go through the trunk TOGETHER as one batch of 2N — 13 convolution
+              launches instead of 26, and twice the tiles per launch for the few-tile layers the Winograd
+              kernel has to stream-K (B = 9: 72-144 workgroups on 256 CUs) — then the five fused tails
+              (g2s_lpips_layer_fwd) on the two halves;
+    backward  hand-written over the PREDICTION half only (the first N samples of every saved activation
+              are a contiguous view): per slice, g2s_lpips_layer_bwd_ex adds the tail's gradient to the
+              one arriving through the next slice's max pool and applies the ReLU gate of the slice's
+              last convolution in the same launch; then data-gradient GEMMs with the ReLU gates of the
+              inner convolutions between them, the max-pool backward from the saved input.
+    Same arithmetic as PNetLin's op-by-op form (lpips/networks_basic.py:64-92); tested against the
+    reference's own run (tests/golden/lpips.npz)."""
+
+    SPLIT_FORWARD = False
+
+    @staticmethod
+    def forward(ctx, pred, target, net):
+        from .modconv import conv_bias_act_raw
+        N = pred.shape[0]
+        sl = net.scaling_layer
+        x = (torch.cat([pred, target], 0) - sl.shift) / sl.scale
+        L = _lib.load()
+        acc = torch.zeros(N, dtype=torch.float32, device=pred.device)
+        saved = []
+        for si in range(5):
+            entry = {"pool_in": None, "convs": []}
+            for mod in getattr(net.net, f"slice{si + 1}"):
+                if isinstance(mod, nn.MaxPool2d):
+                    entry["pool_in"] = x
+                    B, C_, H, W = x.shape
+                    y = torch.empty((B, C_, H // 2, W // 2), dtype=torch.float32, device=x.device)
+                    _lib.check(L.g2s_maxpool2x2_fwd(_lib.ptr(x), _lib.ptr(y), B * C_, H, W, _lib.stream()))
+                    x = y
+                elif isinstance(mod, nn.Conv2d):
+                    if _VggLpips.SPLIT_FORWARD:   # debugging aid: the two halves as separate launches
+                        x = torch.cat([conv_bias_act_raw(x[:N], mod.weight, mod.bias),
+                                       conv_bias_act_raw(x[N:], mod.weight, mod.bias)], 0)
+                    else:
+                        x = conv_bias_act_raw(x, mod.weight, mod.bias)
+                    entry["convs"].append((mod.weight, x))
+            wv = getattr(net, f"lin{si}").model[-1].weight.reshape(-1).contiguous()
+            C_, HW = x.shape[1], x.shape[2] * x.shape[3]
+            _lib.check(L.g2s_lpips_layer_fwd(_lib.ptr(x[:N]), _lib.ptr(x[N:]), _lib.ptr(wv), _lib.ptr(acc),
+                                             N, C_, HW, _lib.stream()))
+            entry["lin"] = wv
+            saved.append(entry)
+        ctx.saved, ctx.N, ctx.scale = saved, N, sl.scale
+        return acc.view(-1, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .modconv import PLAIN, modconv_raw, relu_gate
+        L = _lib.load()
+        N = ctx.N
+        gout = gout.contiguous().view(-1)
+        g = None
+        for si in range(4, -1, -1):
+            e = ctx.saved[si]
+            y = e["convs"][-1][1]
+            C_, HW = y.shape[1], y.shape[2] * y.shape[3]
+            gn = torch.empty((N,) + tuple(y.shape[1:]), dtype=torch.float32, device=y.device)
+            # (gradient from the next slice + this slice's tail) * (y > 0): the last convolution's ReLU
+            _lib.check(L.g2s_lpips_layer_bwd_ex(_lib.ptr(y[:N]), _lib.ptr(y[N:]), _lib.ptr(e["lin"]), _lib.ptr(gout),
+                                                _lib.ptr(g), 1, _lib.ptr(gn), N, C_, HW, _lib.stream()))
+            g = gn
+            convs = e["convs"]
+            for ci in range(len(convs) - 1, -1, -1):
+                w, yc = convs[ci]
+                if ci != len(convs) - 1:
+                    g = relu_gate(g, yc[:N])
+                g = modconv_raw(g, w, None, None, PLAIN, 1)
+            if e["pool_in"] is not None:
+                xin = e["pool_in"]
+                B2, C2, H, W = xin.shape
+                gx = torch.empty((N, C2, H, W), dtype=torch.float32, device=xin.device)
+                _lib.check(L.g2s_maxpool2x2_bwd(_lib.ptr(xin[:N]), _lib.ptr(g.contiguous()), _lib.ptr(gx), N * C2, H, W,
+                                                _lib.stream()))
+                g = gx
+        return g / ctx.scale, None, None
+
+
 def max_pool_2x2(mod, x):
     """`mod(x)` for nn.MaxPool2d(2, 2): the libg2s kernels on CUDA float32 maps with even H and W % 8 == 0."""
     if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0
@@ -147,6 +235,8 @@ class NetLinLayer(nn.Module):
 class PNetLin(nn.Module):
     """networks_basic.py:27-92 for pnet_type='vgg', lpips=True, spatial=False, version 0.1."""
 
+    ONE_NODE = True   # the whole metric as one autograd node with a hand-written backward (_VggLpips)
+
     def __init__(self):
         super().__init__()
         self.scaling_layer = ScalingLayer()
@@ -167,6 +257,12 @@ class PNetLin(nn.Module):
         that needs a gradient)."""
         fused = in0.is_cuda and not in0.requires_grad and not any(
             getattr(self, f"lin{k}").model[-1].weight.requires_grad for k in range(5))
+        if (fused and self.ONE_NODE and in0.dtype == torch.float32 and in0.shape == in1.shape
+                and in0.shape[2] % 16 == 0 and in0.shape[3] % 64 == 0
+                and not any(p.requires_grad for p in self.net.parameters())
+                and all(_pool_ok(m) for s_ in range(1, 6) for m in getattr(self.net, f"slice{s_}")
+                        if isinstance(m, nn.MaxPool2d))):
+            return _VggLpips.apply(in1.contiguous(), in0.contiguous(), self)
         if not fused:
             f0, f1 = self.features(in0), self.features(in1)
             val = 0

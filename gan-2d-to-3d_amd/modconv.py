@@ -352,6 +352,30 @@ def conv2d(x, w, mode):
     return PlainConvFunction.apply(x, w, mode)
 
 
+def conv_bias_act_raw(x, w, bias, mode=PLAIN, alpha=0.0, gain=1.0):
+    """gain * leaky_relu(conv(x, w) + bias, alpha) as ONE launch, outside autograd (Winograd / direct /
+    fp16-operand kernel by the same choice as everywhere)."""
+    x, w, bias = x.contiguous(), w.contiguous(), bias.contiguous()
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    oh, ow = out_size(H, k, mode), out_size(W, k, mode)
+    choice = None if OPERANDS == "f16" else wino_choice(x, w, mode, 0, 1)
+    if OPERANDS == "f16" or choice is not None:
+        y = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device)
+        if OPERANDS == "f16":
+            _f16_launch(x, w, None, None, bias, mode, 0, 1, alpha, gain, y)
+        else:
+            _wino_launch(x, w, None, None, bias, 0, 1, alpha, gain, y, choice)
+        return y
+    return _direct_launch(x, w, None, None, bias, mode, 0, 1, alpha, gain, (B, Cout, oh, ow))
+
+
+def relu_gate(g, y, alpha=0.0, gain=1.0):
+    """Backward of y = gain * leaky_relu(., alpha) from the saved OUTPUT: g * (y > 0 ? gain : alpha * gain)."""
+    from .plugins import fused
+    return fused.fused_bias_act(g.contiguous(), g.new_empty(0), y, 3, 1, alpha, gain)
+
+
 class ConvBiasActFunction(Function):
     """gain * leaky_relu(conv(x, w) + bias, alpha) for a FROZEN network (no weight / bias gradient):
     the VGG16 trunk of LPIPS (conv3x3 + bias + ReLU, lpips/pretrained_networks.py:97-135) and the
@@ -361,19 +385,7 @@ class ConvBiasActFunction(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, mode, alpha, gain):
-        x, w, bias = x.contiguous(), w.contiguous(), bias.contiguous()
-        B, Cin, H, W = x.shape
-        Cout, _, k, _ = w.shape
-        oh, ow = out_size(H, k, mode), out_size(W, k, mode)
-        choice = None if OPERANDS == "f16" else wino_choice(x, w, mode, 0, 1)
-        if OPERANDS == "f16" or choice is not None:
-            y = torch.empty((B, Cout, oh, ow), dtype=torch.float32, device=x.device)
-            if OPERANDS == "f16":
-                _f16_launch(x, w, None, None, bias, mode, 0, 1, alpha, gain, y)
-            else:
-                _wino_launch(x, w, None, None, bias, 0, 1, alpha, gain, y, choice)
-        else:
-            y = _direct_launch(x, w, None, None, bias, mode, 0, 1, alpha, gain, (B, Cout, oh, ow))
+        y = conv_bias_act_raw(x, w, bias, mode, alpha, gain)
         ctx.save_for_backward(w, y)
         ctx.cfg = (mode, float(alpha), float(gain))
         return y

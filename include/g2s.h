@@ -358,6 +358,13 @@ int g2s_lpips_layer_fwd(const float *f0, const float *f1, const float *w, float 
                         int HW, g2s_stream_t stream);
 int g2s_lpips_layer_bwd(const float *f0, const float *f1, const float *w, const float *gout,
                         float *g0, int N, int C, int HW, g2s_stream_t stream);
+/* The same inside the VGG trunk's hand-written backward (gan2shape_amd/lpips.py): f0 is the ReLU output
+ * of the slice's last convolution (pretrained_networks.py:97-135), so the gradient that reaches it is
+ * g_in (from the next slice through its max pool; NULL for the last slice) + this layer's tail, passed
+ * only where f0 > 0 when relu_gate = 1 — one launch instead of tail + add + ReLU backward. */
+int g2s_lpips_layer_bwd_ex(const float *f0, const float *f1, const float *w, const float *gout,
+                           const float *g_in, int relu_gate, float *g0, int N, int C, int HW,
+                           g2s_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Masked L1 (csrc/losses.hip): the numerator of PhotometricLoss and of every DiscriminatorLoss level
