@@ -235,7 +235,41 @@ __global__ __launch_bounds__(256) void add_bias_scale_kernel(const float *a, con
     }
 }
 
+// y = clamp(x, lo, hi) and its backward gx = g where lo <= x <= hi (torch's rule, bounds inclusive), one
+// launch each; dir 0: forward (g unused), 1: backward.
+__global__ void clamp_kernel(const float *__restrict__ x, const float *__restrict__ g, float *__restrict__ y,
+                             int64_t n, float lo, float hi, int dir) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n && (((uintptr_t)(x + i) | (uintptr_t)(y + i) | (uintptr_t)(dir ? g + i : x + i)) & 15) == 0) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + i);
+            float4 o;
+            if (dir) {
+                const float4 q = *reinterpret_cast<const float4 *>(g + i);
+                o = float4{(v.x >= lo && v.x <= hi) ? q.x : 0.0f, (v.y >= lo && v.y <= hi) ? q.y : 0.0f,
+                           (v.z >= lo && v.z <= hi) ? q.z : 0.0f, (v.w >= lo && v.w <= hi) ? q.w : 0.0f};
+            } else {
+                auto cl = [&](float t) { return t < lo ? lo : (t > hi ? hi : t); };   // NaN stays NaN, as in torch
+                o = float4{cl(v.x), cl(v.y), cl(v.z), cl(v.w)};
+            }
+            *reinterpret_cast<float4 *>(y + i) = o;
+        } else {
+            for (int64_t j = i; j < i + 4 && j < n; j++)
+                y[j] = dir ? ((x[j] >= lo && x[j] <= hi) ? g[j] : 0.0f) : (x[j] < lo ? lo : (x[j] > hi ? hi : x[j]));
+        }
+    }
+}
+
 }  // namespace g2s
+
+extern "C" int g2s_clamp(const float *x, const float *g, float *y, int64_t n, float lo, float hi, int backward,
+                         g2s_stream_t stream) {
+    G2S_REQUIRE(x && y && n > 0 && (!backward || g) && lo <= hi, "bad argument");
+    const int64_t quads = (n + 3) / 4;
+    const int blocks = (int)std::min<int64_t>((quads + 255) / 256, 256 * 8);
+    g2s::clamp_kernel<<<blocks, 256, 0, g2s::as_stream(stream)>>>(x, g, y, n, lo, hi, backward ? 1 : 0);
+    return g2s::check_launch("g2s_clamp");
+}
 
 extern "C" int g2s_add_bias_scale(const float *a, const float *b, const float *bias, float *y, int64_t n, int64_t hw,
                                   int C, float scale, g2s_stream_t stream) {

@@ -18,6 +18,7 @@ _p, _i, _f, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
 SIGNATURES = {
     "g2s_abi_version": (_i, []),
     "g2s_last_error": (C.c_char_p, []),
+    "g2s_clamp": (_i, [_p, _p, _p, _i64, _f, _f, _i, _p]),
     "g2s_set_deterministic": (_i, [_i]),
     "g2s_get_deterministic": (_i, []),
     "g2s_raster_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -134,6 +134,35 @@ class _AddBiasScale(Function):
         return gs, (gs if ctx.needs_input_grad[1] else None), gbias, None
 
 
+class _Clamp(Function):
+    """torch.clamp(x, lo, hi) with a one-launch backward (g2s_clamp): autograd's ClampBackward runs
+    ge + le + logical_and + where (+ a fill) per clamp, and a step has four of them."""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(_lib.load().g2s_clamp(_lib.ptr(x), None, _lib.ptr(y), x.numel(), float(lo), float(hi), 0, _lib.stream()))
+        ctx.save_for_backward(x)
+        ctx.bounds = (float(lo), float(hi))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        _lib.check(_lib.load().g2s_clamp(_lib.ptr(x), _lib.ptr(g.contiguous()), _lib.ptr(gx), x.numel(), *ctx.bounds, 1,
+                                         _lib.stream()))
+        return gx, None, None
+
+
+def clamp(x, lo, hi):
+    """x.clamp(min=lo, max=hi); CUDA float32 tensors that need a gradient take the libg2s pair."""
+    if x.is_cuda and x.dtype == torch.float32 and x.requires_grad and x.numel() > 0:
+        return _Clamp.apply(x, lo, hi)
+    return x.clamp(min=lo, max=hi)
+
+
 def add_bias_scale(a, b=None, bias=None, scale=1.0):
     """(a + b + bias) * scale for [B, C, H, W] tensors (bias broadcast over channels, any shape with C
     elements): ToRGB's `conv + bias + upsample(skip)` (stylegan2-pytorch/model.py:371-377) and the

@@ -156,7 +156,8 @@ class Renderer():
         warped_depth = self.renderer.render_depth(grid_3d, faces)
         # allow some margin out of valid range
         margin = (self.max_depth - self.min_depth) / 2
-        return warped_depth.clamp(min=self.min_depth - margin, max=self.max_depth + margin)
+        from ..op import clamp
+        return clamp(warped_depth, self.min_depth - margin, self.max_depth + margin)
 
     def get_normal_from_depth(self, depth):
         b, h, w = depth.shape

@@ -137,6 +137,13 @@ int g2s_maxpool2x2_bwd(const float *x, const float *gy, float *gx, int64_t plane
 int g2s_add_bias_scale(const float *a, const float *b, const float *bias, float *y, int64_t n, int64_t hw, int C,
                        float scale, g2s_stream_t stream);
 
+/* torch.clamp(x, lo, hi) of the step's image / depth clamps (GAN2Shape/model.py:150,270, renderer.py:123-124)
+ * and its backward as ONE launch each (autograd's ClampBackward is five: ge, le, logical_and, where, fill).
+ * backward = 0: y = min(max(x, lo), hi);  backward = 1: y = g where lo <= x <= hi, else 0 (torch's rule;
+ * NaN in x: forward gives NaN like torch, backward 0).  x, g, y [n] f32. */
+int g2s_clamp(const float *x, const float *g, float *y, int64_t n, float lo, float hi, int backward,
+              g2s_stream_t stream);
+
 /* StyledConv tail in one pass (stylegan2-pytorch/model.py:349-355: NoiseInjection then
  * FusedLeakyReLU): y = lrelu_alpha(x + noise_w * noise[hw] + bias[c]) * scale.
  * x,y [B, C, HW] f32; noise [HW] f32 (one map broadcast over B and C) or NULL;

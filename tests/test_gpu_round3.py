@@ -115,3 +115,24 @@ def test_zero_pool_hands_out_cleared_slices_and_results_do_not_change(L):
         assert float((y.double().cpu() - ref).norm()) <= 2e-5 * float(ref.norm())
     # a large layer overwrites its output: never taken from the pool
     assert L.g2s_modconv_needs_zero(8, 128, 128, 128, 128, 3, 0, 0, 0, 0) == 0
+
+
+def test_clamp_matches_torch_including_the_bounds(L):
+    """g2s_clamp: forward bit-equal to torch.clamp, backward = torch's rule (gradient passes where
+    lo <= x <= hi, bounds inclusive), odd sizes and unaligned views included."""
+    from gan2shape_amd.op import clamp
+    torch.manual_seed(0)
+    for shape in [(8, 3, 128, 128), (1, 128, 128), (3, 5, 7)]:
+        x0 = torch.randn(*shape, device="cuda") * 1.5
+        x0.view(-1)[:6] = torch.tensor([-1.0, 1.0, -1.0000001, 1.0000001, 0.0, float("nan")], device="cuda")
+        g = torch.randn_like(x0)
+        xa = x0.clone().requires_grad_(True)
+        xb = x0.clone().requires_grad_(True)
+        ya, yb = clamp(xa, -1, 1), xb.clamp(min=-1, max=1)
+        assert torch.equal(torch.nan_to_num(ya.detach(), nan=7.0), torch.nan_to_num(yb.detach(), nan=7.0))
+        ya.backward(g)
+        yb.backward(g)
+        assert torch.equal(xa.grad, xb.grad)
+    x = torch.randn(1001, device="cuda")[1:].requires_grad_(True)      # 4-byte aligned only
+    y = clamp(x, -0.5, 0.25)
+    assert torch.equal(y.detach(), x.detach().clamp(-0.5, 0.25))
