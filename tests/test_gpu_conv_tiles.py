@@ -242,7 +242,9 @@ def test_winograd_weights_follow_the_tensor_version(L):
 @pytest.mark.parametrize("transpose", [0, 1])
 @pytest.mark.parametrize("B,cin,cout,H,k,mode", [
     (4, 128, 128, 64, 3, PLAIN), (2, 512, 512, 16, 3, PLAIN), (2, 256, 128, 32, 3, UP2), (2, 128, 256, 33, 3, DOWN2),
-    (2, 128, 3, 64, 1, PLAIN), (3, 70, 50, 19, 3, PLAIN), (2, 40, 24, 9, 3, UP2), (2, 3, 64, 32, 3, PLAIN)])
+    (2, 128, 3, 64, 1, PLAIN), (3, 70, 50, 19, 3, PLAIN), (2, 40, 24, 9, 3, UP2), (2, 3, 64, 32, 3, PLAIN),
+    (1, 64, 64, 256, 3, PLAIN),     # config 5's own 256-wide maps: waves without a border lane (quad form)
+    (2, 16, 16, 3, 3, PLAIN)])      # maps narrower than 4: the un-pipelined 3x3 body
 def test_modconv_f16_operands_vs_oracle(L, B, cin, cout, H, k, mode, transpose):
     """g2s_modconv_f16 (fp16 operands, fp32 accumulation — BASELINE config 5) against the fp32
     oracle: the operand rounding (2^-11 relative, random sign) leaves ~1e-3 of the output scale after
