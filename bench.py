@@ -379,10 +379,16 @@ def self_launch(n_ranks):
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
     line = None
     for out_line in proc.stdout.splitlines():
+        obj = None
         try:
-            if "metric" in json.loads(out_line):
-                line = out_line
+            obj = json.loads(out_line)
         except ValueError:
+            pass
+        # a library may print to stdout too (gloo / RCCL banners; a bare number parses as JSON):
+        # only a JSON OBJECT with the contract's keys is the result line
+        if isinstance(obj, dict) and "metric" in obj and "value" in obj:
+            line = out_line
+        else:
             sys.stderr.write(out_line + "\n")
     if proc.returncode == 0 and line is None:
         sys.stderr.write("[bench] the ranks exited without printing a result line\n")
