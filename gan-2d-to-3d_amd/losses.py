@@ -57,10 +57,121 @@ def _masked_l1(a, b, weight):
     return _weighted_mean((a - b).abs(), weight)
 
 
+class _DFeatureL1(torch.autograd.Function):
+    """The whole discriminator-feature loss as ONE autograd node (frozen D, gradient-free real branch):
+
+    forward   fake and real images go through the first `count` + 1 blocks of D TOGETHER as one batch of
+              2N (13 convolution launches instead of 26 at size 128, 8 blurs instead of 16, and twice the
+              work per launch for the few-tile 16^2 / 8^2 layers), then the masked feature L1 of every
+              level on the two halves (g2s_weighted_l1_fwd);
+    backward  hand-written over the FAKE half only (the first N samples of every saved activation are a
+              contiguous view): per ResBlock (stylegan2-pytorch/model.py:679-697) the leaky-ReLU gates
+              from the saved outputs, the stride-2 / stride-1 data-gradient GEMMs, the blurs' adjoints,
+              and the residual join (a + b) / sqrt(2) as one launch.
+    Same arithmetic as DiscriminatorLoss.__call__'s op-by-op form below."""
+
+    @staticmethod
+    def forward(ctx, fake, real, D, count, weights):
+        from . import lib as _lib
+        from .op import add_bias_scale
+        N = fake.shape[0]
+        x = torch.cat([fake, real], 0)
+        L = _lib.load()
+        first = D.convs[0]
+        y0 = first(x)
+        blocks, out = [], y0
+        nums, dens = [], []
+        for i in range(1, count + 1):
+            blk = D.convs[i]
+            y1 = blk.conv1(out)
+            y2 = blk.conv2(y1)
+            sk = blk.skip(out)
+            nxt = add_bias_scale(y2, sk, None, 2 ** -0.5)
+            blocks.append((blk, out.shape[2:], y1, y2))
+            out = nxt
+            B2, C, H, W = out.shape
+            w = weights[i - 1]
+            wc = None if w is None else w.contiguous()
+            num = torch.zeros((), dtype=torch.float32, device=out.device)
+            _lib.check(L.g2s_weighted_l1_fwd(_lib.ptr(out[:N]), _lib.ptr(out[N:]), _lib.ptr(wc), _lib.ptr(num), N, C,
+                                             H * W, _lib.stream()))
+            den = (wc.sum() * C) if wc is not None else torch.tensor(float(N * C * H * W), device=out.device)
+            nums.append(num)
+            dens.append(den)
+            blocks[-1] = blocks[-1] + (out, wc)
+        ctx.D, ctx.N, ctx.first, ctx.y0 = D, N, first, y0
+        ctx.blocks, ctx.dens = blocks, dens
+        total = nums[0] / dens[0]
+        for n_, d_ in zip(nums[1:], dens[1:]):
+            total = total + n_ / d_
+        return total
+
+    @staticmethod
+    def backward(ctx, g_total):
+        from . import lib as _lib
+        from .modconv import DOWN2, PLAIN, modconv_raw, relu_gate
+        from .op import add_bias_scale
+        from .op.upfirdn2d import upfirdn2d_adjoint
+        L = _lib.load()
+        N = ctx.N
+        slope, gain = 0.2, 2 ** 0.5
+        g = None
+        for (blk, in_hw, y1, y2, feat, wc), den in zip(reversed(ctx.blocks), reversed(ctx.dens)):
+            # masked L1 of this level, gradient w.r.t. the fake half
+            coef = (g_total / den).reshape(1).float().contiguous()
+            B2, C, H, W = feat.shape
+            gl = torch.empty((N, C, H, W), dtype=torch.float32, device=feat.device)
+            _lib.check(L.g2s_weighted_l1_bwd(_lib.ptr(feat[:N]), _lib.ptr(feat[N:]), _lib.ptr(wc), _lib.ptr(coef),
+                                             _lib.ptr(gl), N, C, H * W, _lib.stream()))
+            g = gl if g is None else g + gl
+            # out = (conv2(conv1(x)) + skip(x)) / sqrt(2): both branches keep the common factor, the join applies it
+            conv2, conv1, skip = blk.conv2, blk.conv1, blk.skip
+            w2 = conv2[-2]._w.get(conv2[-2].weight, conv2[-2].scale)
+            w1 = conv1[-2]._w.get(conv1[-2].weight, conv1[-2].scale)
+            ws = skip[-1]._w.get(skip[-1].weight, skip[-1].scale)
+            g2 = relu_gate(g, y2[:N], slope, gain)
+            gb = modconv_raw(g2, w2, None, None, DOWN2, 1)                       # w.r.t. the blurred conv1 output
+            blur2 = conv2[0]
+            gy1 = upfirdn2d_adjoint(gb, blur2.kernel, 1, blur2.down, blur2.pad, y1.shape[2:])
+            g1 = relu_gate(gy1, y1[:N], slope, gain)
+            gx_main = modconv_raw(g1, w1, None, None, PLAIN, 1)
+            gs = modconv_raw(g, ws, None, None, PLAIN, 1)                        # 1x1 on the blur-downsampled input
+            blurs = skip[0]
+            gx_skip = upfirdn2d_adjoint(gs, blurs.kernel, 1, blurs.down, blurs.pad, in_hw)
+            g = add_bias_scale(gx_main, gx_skip, None, 2 ** -0.5)
+        first = ctx.first
+        w0 = first[-2]._w.get(first[-2].weight, first[-2].scale)
+        g0 = relu_gate(g, ctx.y0[:N], slope, gain)
+        gx = modconv_raw(g0, w0, None, None, PLAIN, 1)
+        return gx, None, None, None, None
+
+
+def _d_one_node_ok(D, fake, real, count):
+    from .stylegan2 import ConvLayer, ResBlock
+    from .op import FusedLeakyReLU
+    if not (DiscriminatorLoss.ONE_NODE and isinstance(D, torch.nn.Module) and hasattr(D, "convs")
+            and fake.is_cuda and fake.dtype == torch.float32 and fake.dim() == 4 and fake.shape == real.shape
+            and not real.requires_grad and 1 <= count < len(D.convs)
+            and not any(p.requires_grad for p in D.parameters())):
+        return False
+    first = D.convs[0]
+    if not (isinstance(first, ConvLayer) and len(first) == 2 and isinstance(first[-1], FusedLeakyReLU)):
+        return False
+    for blk in D.convs[1:count + 1]:
+        if not (isinstance(blk, ResBlock) and len(blk.conv1) == 2 and len(blk.conv2) == 3 and len(blk.skip) == 2
+                and isinstance(blk.conv1[-1], FusedLeakyReLU) and isinstance(blk.conv2[-1], FusedLeakyReLU)
+                and blk.conv1[-2].weight.shape[2] == 3 and blk.conv2[-2].weight.shape[2] == 3
+                and blk.skip[-1].weight.shape[2] == 1):
+            return False
+    return True
+
+
 class DiscriminatorLoss():
     """Sum over the first `ftr_num` discriminator feature maps of the L1 distance between the
     features of `fake_img` and `real_img`; a mask is box-averaged down to each feature resolution
     and used as the weight (losses.py:6-36).  The real branch runs without autograd."""
+
+    ONE_NODE = True   # fake and real through D as one batch, hand-written backward (_DFeatureL1)
 
     def __init__(self, ftr_num=4, data_parallel=False):
         if data_parallel:
@@ -71,6 +182,15 @@ class DiscriminatorLoss():
         return D(image, self.ftr_num)[1]
 
     def __call__(self, D, fake_img, real_img, mask=None):
+        if self.ftr_num is not None and _d_one_node_ok(D, fake_img, real_img.detach(), self.ftr_num) and (
+                mask is None or (mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[0] == fake_img.shape[0]
+                                 and mask.shape[2:] == fake_img.shape[2:] and not mask.requires_grad
+                                 and mask.shape[2] % (2 ** self.ftr_num) == 0 and mask.shape[3] % (2 ** self.ftr_num) == 0)):
+            weights, w = [], mask
+            for _ in range(self.ftr_num):      # feature level l lives at 1 / 2^l of the image: 2x2 box averages
+                w = None if w is None else F.avg_pool2d(w, 2, 2)
+                weights.append(w)
+            return _DFeatureL1.apply(fake_img, real_img.detach(), D, self.ftr_num, weights)
         with torch.no_grad():
             real = self._features(D, real_img.detach())
         fake = self._features(D, fake_img)

@@ -57,6 +57,17 @@ class _Resample(Function):
         return gx, None, None, None, None, None
 
 
+def upfirdn2d_adjoint(gy, kernel, up, down, pad, in_hw):
+    """Adjoint of y = upfirdn2d(x, kernel, up, down, pad) applied to `gy` (x was in_hw = (H, W)): the
+    data-gradient, as one launch (what _Resample.backward computes), for hand-written backward passes."""
+    H, W = in_hw
+    kh, kw = kernel.shape
+    oh, ow = gy.shape[2], gy.shape[3]
+    apad = (kw - pad[0] - 1, W * up - ow * down + pad[0] - up + 1,
+            kh - pad[0] - 1, H * up - oh * down + pad[0] - up + 1)
+    return _Resample.apply(gy.contiguous(), _flip(kernel), (down, down), (up, up), apad, (H, W))
+
+
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     """Upsample by `up` (zero insertion), pad by `pad` = (before, after) on both axes (negative =
     crop), filter with the 2-D FIR `kernel`, keep every `down`-th sample."""

@@ -218,25 +218,37 @@ def test_trainer_fit_and_checkpoint_roundtrip(trainer, tmp_path):
 
 
 def test_lpips_fused_tail_matches_reference_form():
-    """g2s_lpips_layer_* vs the op-by-op form of lpips/networks_basic.py:64-92 (same module, the
-    unfused branch is taken when the target requires a gradient)."""
+    """The one-node LPIPS (lpips._VggLpips: fused tails, hand-written trunk backward) vs the op-by-op form
+    of lpips/networks_basic.py:64-92 (same module, the unfused branch is taken when the target requires a
+    gradient).  The two halves of the trunk forward are launched apart here, so that both forms see
+    bit-identical activations; what the batch-2N forward adds (ReLU / max-pool tie decisions) is measured
+    in tests/test_gpu_golden.py::test_lpips_gpu_vs_reference_run."""
     import gan2shape_amd  # noqa: F401
+    from gan2shape_amd import lpips as lp
     from gan2shape_amd.lpips import PerceptualLoss
     torch.manual_seed(0)
     p = PerceptualLoss().cuda()
     with torch.no_grad():
         for k in range(5):
             getattr(p.net, f"lin{k}").model[-1].weight.uniform_(0.0, 1.0)
-    for B in (1, 3):
-        pred = (torch.rand(B, 3, 64, 64, device="cuda") * 2 - 1).requires_grad_(True)
-        target = torch.rand(B, 3, 64, 64, device="cuda") * 2 - 1
-        fused = p(pred, target)
-        (g_fused,) = torch.autograd.grad(fused.sum(), pred)
-        ref = p(pred, target.clone().requires_grad_(True))
-        (g_ref,) = torch.autograd.grad(ref.sum(), pred)
-        assert fused.shape == ref.shape == (B, 1, 1, 1)
-        torch.testing.assert_close(fused, ref, rtol=2e-5, atol=1e-7)
-        torch.testing.assert_close(g_fused, g_ref, rtol=2e-4, atol=2e-6 * float(g_ref.abs().max()) + 1e-9)
+    lp._VggLpips.SPLIT_FORWARD = True
+    try:
+        for B in (1, 3):
+            pred = (torch.rand(B, 3, 64, 64, device="cuda") * 2 - 1).requires_grad_(True)
+            target = torch.rand(B, 3, 64, 64, device="cuda") * 2 - 1
+            fused = p(pred, target)
+            (g_fused,) = torch.autograd.grad(fused.sum(), pred)
+            ref = p(pred, target.clone().requires_grad_(True))
+            (g_ref,) = torch.autograd.grad(ref.sum(), pred)
+            assert fused.shape == ref.shape == (B, 1, 1, 1)
+            torch.testing.assert_close(fused, ref, rtol=2e-5, atol=1e-7)
+            torch.testing.assert_close(g_fused, g_ref, rtol=2e-4, atol=2e-5 * float(g_ref.abs().max()) + 1e-9)
+    finally:
+        lp._VggLpips.SPLIT_FORWARD = False
+    # and the batch-2N forward gives the same VALUE (decisions may move gradient patches, not the sum)
+    pred = (torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1)
+    target = torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1
+    torch.testing.assert_close(p(pred, target), p(pred, target.clone().requires_grad_(True)), rtol=2e-5, atol=1e-7)
 
 
 def test_fused_geometry_matches_torch_path():
