@@ -37,6 +37,28 @@ from .renderer import Renderer
 from .stylegan2 import Discriminator, Generator
 
 
+_WSUM_CONST = {}
+
+
+def weighted_total(terms):
+    """sum_i w_i * mean(t_i) over `terms` = [(w_i, t_i)] (t_i a scalar loss or a vector of per-sample
+    losses) as TWO launches forward and ONE backward: one concatenation and one dot product with a
+    constant weight vector, instead of a mean / multiply / add (and their backward nodes) per term.
+    Same value up to the order of a handful of fp32 additions."""
+    flat = [t.reshape(-1) for _, t in terms]
+    # a weight is a number (weight of the term's MEAN) or a tuple of per-element weights
+    per_elem = [tuple(float(v) for v in w) if isinstance(w, (tuple, list)) else (float(w) / f.numel(),) * f.numel()
+                for (w, _), f in zip(terms, flat)]
+    assert all(len(pe) == f.numel() for pe, f in zip(per_elem, flat))
+    key = (tuple(per_elem), flat[0].device)
+    wv = _WSUM_CONST.get(key)
+    if wv is None:
+        if len(_WSUM_CONST) > 64:
+            _WSUM_CONST.clear()
+        wv = _WSUM_CONST[key] = torch.tensor([v for pe in per_elem for v in pe], dtype=torch.float32).to(flat[0].device)
+    return torch.dot(torch.cat(flat), wv)
+
+
 class GAN2Shape(nn.Module):
     NETS = ['lighting', 'viewpoint', 'depth', 'albedo', 'offset_encoder']
 
@@ -282,13 +304,13 @@ class GAN2Shape(nn.Module):
         recon_b, mask_b = self._head(recon_im, b), self._head(recon_im_mask, b)   # model.py:150: b = 1
         loss_l1_im = self.photometric_loss(recon_b, images, mask=mask_b)
         perc_pair = (recon_b * mask_b, images * mask_b)
-        loss_smooth = self.smooth_loss(depth) + self.smooth_loss(diffuse_shading)
+        smooth_terms = [(self.lam_smooth, self.smooth_loss(depth)), (self.lam_smooth, self.smooth_loss(diffuse_shading))]
         canon_mask = None if len(images) == 1 else [None] * len(images)
         collected = (normal, lighting_a, lighting_b, albedo, depth, canon_mask)
-        if kwargs.get('_defer_perc'):  # caller adds lam_perc * mean(LPIPS(*perc_pair))
-            return loss_l1_im + self.lam_smooth * loss_smooth, collected, perc_pair
-        loss_perc_im = torch.mean(self.perceptual_loss(*perc_pair))
-        loss_total = loss_l1_im + self.lam_perc * loss_perc_im + self.lam_smooth * loss_smooth
+        if kwargs.get('_defer_perc'):  # caller adds lam_perc * mean(LPIPS(*perc_pair)) and sums the terms
+            return [(1.0, loss_l1_im)] + smooth_terms, collected, perc_pair
+        # loss_total = loss_l1_im + lam_perc * mean(perc) + lam_smooth * (smooth(depth) + smooth(shading))
+        loss_total = weighted_total([(1.0, loss_l1_im), (self.lam_perc, self.perceptual_loss(*perc_pair))] + smooth_terms)
         return loss_total, collected
 
     # ------------------------------------------------------------------ step 2
@@ -438,12 +460,12 @@ class GAN2Shape(nn.Module):
         loss_l1_im = self.photometric_loss(recon_b, projected_samples, mask=mask_b)
         pred, target = recon_b * mask_b, projected_samples * mask_b
         if perc1 is not None:
-            perc = self.perceptual_loss(torch.cat([perc1[0], pred], 0), torch.cat([perc1[1], target], 0))
-            perc_1, perc_n = perc.split([1, b])
-            loss_perc_1, loss_perc_im = torch.mean(perc_1), torch.mean(perc_n)
-            step1_loss = step1_loss + self.lam_perc * loss_perc_1
-        else:
-            loss_perc_im = torch.mean(self.perceptual_loss(pred, target))
+            # step1_loss arrives as its list of terms; LPIPS ran once on (image, n samples): its first entry
+            # is the inner step-1 term (mean over 1), the other b the projected samples' (mean over b)
+            perc = self.perceptual_loss(torch.cat([perc1[0], pred], 0), torch.cat([perc1[1], target], 0)).reshape(-1)
+            terms = step1_loss + [(1.0, loss_l1_im), ((self.lam_perc,) + (self.lam_perc / b,) * b, perc)]
+            return weighted_total(terms), None
+        loss_perc_im = torch.mean(self.perceptual_loss(pred, target))
         return step1_loss + loss_l1_im + self.lam_perc * loss_perc_im, None
 
     # ------------------------------------------------------------------ evaluation / checkpoints
