@@ -350,7 +350,7 @@ class GAN2Shape(nn.Module):
         self.loss_rec = self.discriminator_loss(self.discriminator, projected_image, pseudo_im,
                                                 mask=mask)
         self.loss_latent_norm = torch.mean(offset ** 2)
-        loss_total = self.loss_l1 + self.loss_rec + self.lam_regular * self.loss_latent_norm
+        loss_total = weighted_total([(1.0, self.loss_l1), (1.0, self.loss_rec), (self.lam_regular, self.loss_latent_norm)])
         return loss_total, (projected_image.detach(), mask.detach())
 
     def latent_projection(self, image, gan_im, latent, center_w, center_h, F1_d):

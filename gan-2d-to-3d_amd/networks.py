@@ -7,6 +7,7 @@ PSPNet / BiSeNet / ResNet (networks.py:247-586) only feed the one-shot masking m
 of scope.  The debug gradient alerts (debug_grad_updates.py) are dropped; `debug` is accepted and
 ignored.
 """
+import torch
 import torch.nn as nn
 
 
@@ -81,6 +82,26 @@ def pair_parameters(net_a, net_b):
     return n
 
 
+class _SplitHalves(torch.autograd.Function):
+    """x [B, 2c, H, W] -> (x[:, :c], x[:, c:]) as contiguous tensors; backward = ONE concatenation (two
+    `.contiguous()` slices cost a zero-fill + copy each and an add in backward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        c = x.shape[1] // 2
+        return x[:, :c].contiguous(), x[:, c:].contiguous()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None
+        if ga is None:
+            ga = torch.zeros_like(gb)
+        if gb is None:
+            gb = torch.zeros_like(ga)
+        return torch.cat([ga, gb], 1)
+
+
 def run_fused_pair(mods_a, mods_b, x, train_a=True, train_b=True):
     """Two structurally identical module lists on the SAME input as one pass: activations carry the
     channels of net a followed by those of net b, convolutions run as grouped launches
@@ -125,8 +146,7 @@ def run_fused_pair(mods_a, mods_b, x, train_a=True, train_b=True):
     if groups == 1:
         xa = xb = x
     else:
-        c = x.shape[1] // 2
-        xa, xb = x[:, :c].contiguous(), x[:, c:].contiguous()
+        xa, xb = _SplitHalves.apply(x)
     def tail(mods, xin, train):
         if i >= len(mods):
             return xin if train else xin.detach()
