@@ -32,6 +32,7 @@ SOURCES = {
     "pool.hip": [],
     "losses.hip": [],
     "geometry.hip": ["-ffp-contract=off"],
+    "grid_sample.hip": ["-ffp-contract=off"],
     "groupnorm.hip": [],
     "conv_wgrad.hip": [],
     "adam.hip": [],

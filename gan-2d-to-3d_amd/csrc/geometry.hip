@@ -101,28 +101,31 @@ __global__ __launch_bounds__(256) void warp_verts_bwd(const float *__restrict__ 
                                                       float *__restrict__ gdepth,
                                                       float *__restrict__ gRt, int P, int need_rt) {
     __shared__ float red[4];
-    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    const bool ok = p < P;
+    const int b = blockIdx.y;
     const float *r = R + b * 9;
-    float g0 = 0, g1 = 0, g2 = 0, x = 0, y = 0, z = 0;
-    if (ok) {
+    float s[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // one pass when the grid covers P (the default launch); a single workgroup per item strides over
+    // all pixels in deterministic mode, so every per-item sum has one fixed order
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
         const float *g = gverts + ((size_t)b * P + p) * 3;
-        g0 = g[0]; g1 = g[1]; g2 = g[2];
+        const float g0 = g[0], g1 = g[1], g2 = g[2];
         const float d = depth[(size_t)b * P + p];
         const float rx = rays[3 * p], ry = rays[3 * p + 1], rz = rays[3 * p + 2];
-        x = rx * d; y = ry * d; z = rz * d - rcd;
+        const float x = rx * d, y = ry * d, z = rz * d - rcd;
         // gX = R^T g ; gd = gX . ray
         const float gx = r[0] * g0 + r[3] * g1 + r[6] * g2;
         const float gy = r[1] * g0 + r[4] * g1 + r[7] * g2;
         const float gz = r[2] * g0 + r[5] * g1 + r[8] * g2;
         gdepth[(size_t)b * P + p] = gx * rx + gy * ry + gz * rz;
+        s[0] += g0 * x; s[1] += g0 * y; s[2] += g0 * z;
+        s[3] += g1 * x; s[4] += g1 * y; s[5] += g1 * z;
+        s[6] += g2 * x; s[7] += g2 * y; s[8] += g2 * z;
+        s[9] += g0; s[10] += g1; s[11] += g2;
     }
     if (!need_rt) return;
     float *o = gRt + b * 12;
-    block_atomic_add(g0 * x, o + 0, red); block_atomic_add(g0 * y, o + 1, red); block_atomic_add(g0 * z, o + 2, red);
-    block_atomic_add(g1 * x, o + 3, red); block_atomic_add(g1 * y, o + 4, red); block_atomic_add(g1 * z, o + 5, red);
-    block_atomic_add(g2 * x, o + 6, red); block_atomic_add(g2 * y, o + 7, red); block_atomic_add(g2 * z, o + 8, red);
-    block_atomic_add(g0, o + 9, red); block_atomic_add(g1, o + 10, red); block_atomic_add(g2, o + 11, red);
+#pragma unroll
+    for (int k = 0; k < 12; k++) block_atomic_add(s[k], o + k, red);
 }
 
 // ------------------------------------------------------------------ depth -> inverse-warped 2-D grid
@@ -158,34 +161,35 @@ __global__ __launch_bounds__(256) void inv_warp_grid_bwd(const float *__restrict
                                                          float *__restrict__ gdepth,
                                                          float *__restrict__ gRt, int P, int need_rt) {
     __shared__ float red[4];
-    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    const bool ok = p < P;
+    const int b = blockIdx.y;
     const float *r = R + b * 9, *tt = t + b * 3;
-    float zx = 0, zy = 0, zz = 0, gyx = 0, gyy = 0, gyz = 0, gzx = 0, gzy = 0, gzz = 0;
-    if (ok) {
+    float s[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
         const float d = depth[(size_t)b * P + p];
         const float rx = rays[3 * p], ry = rays[3 * p + 1], rz = rays[3 * p + 2];
-        zx = rx * d - tt[0]; zy = ry * d - tt[1]; zz = (rz * d - tt[2]) - rcd;
+        const float zx = rx * d - tt[0], zy = ry * d - tt[1], zz = (rz * d - tt[2]) - rcd;
         const float yx = zx * r[0] + zy * r[3] + zz * r[6];
         const float yy = zx * r[1] + zy * r[4] + zz * r[7];
         const float yz = (zx * r[2] + zy * r[5] + zz * r[8]) + rcd;
         const float *g = ggrid + ((size_t)b * P + p) * 2;
         const float gu = g[0] * K.sx, gv = g[1] * K.sy;
         const float ga = gu * K.k00 + gv * K.k10, gb = gu * K.k01 + gv * K.k11;
-        gyx = ga / yz; gyy = gb / yz; gyz = -(ga * yx + gb * yy) / (yz * yz);
+        const float gyx = ga / yz, gyy = gb / yz, gyz = -(ga * yx + gb * yy) / (yz * yz);
         // gZ = R gY
-        gzx = r[0] * gyx + r[1] * gyy + r[2] * gyz;
-        gzy = r[3] * gyx + r[4] * gyy + r[5] * gyz;
-        gzz = r[6] * gyx + r[7] * gyy + r[8] * gyz;
+        const float gzx = r[0] * gyx + r[1] * gyy + r[2] * gyz;
+        const float gzy = r[3] * gyx + r[4] * gyy + r[5] * gyz;
+        const float gzz = r[6] * gyx + r[7] * gyy + r[8] * gyz;
         gdepth[(size_t)b * P + p] = gzx * rx + gzy * ry + gzz * rz;
+        // Y_k = sum_j R_jk (Z - c)_j  =>  gR_jk = (Z - c)_j gY_k
+        s[0] += zx * gyx; s[1] += zx * gyy; s[2] += zx * gyz;
+        s[3] += zy * gyx; s[4] += zy * gyy; s[5] += zy * gyz;
+        s[6] += zz * gyx; s[7] += zz * gyy; s[8] += zz * gyz;
+        s[9] -= gzx; s[10] -= gzy; s[11] -= gzz;
     }
     if (!need_rt) return;
     float *o = gRt + b * 12;
-    // Y_k = sum_j R_jk (Z - c)_j  =>  gR_jk = (Z - c)_j gY_k
-    block_atomic_add(zx * gyx, o + 0, red); block_atomic_add(zx * gyy, o + 1, red); block_atomic_add(zx * gyz, o + 2, red);
-    block_atomic_add(zy * gyx, o + 3, red); block_atomic_add(zy * gyy, o + 4, red); block_atomic_add(zy * gyz, o + 5, red);
-    block_atomic_add(zz * gyx, o + 6, red); block_atomic_add(zz * gyy, o + 7, red); block_atomic_add(zz * gyz, o + 8, red);
-    block_atomic_add(-gzx, o + 9, red); block_atomic_add(-gzy, o + 10, red); block_atomic_add(-gzz, o + 11, red);
+#pragma unroll
+    for (int k = 0; k < 12; k++) block_atomic_add(s[k], o + k, red);
 }
 
 // ------------------------------------------------------------------ smoothness loss
@@ -194,18 +198,21 @@ __global__ __launch_bounds__(256) void inv_warp_grid_bwd(const float *__restrict
 __device__ __forceinline__ float sgn(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
 
 __global__ __launch_bounds__(256) void smooth_loss_fwd(const float *__restrict__ pm, float *__restrict__ loss,
-                                                       int H, int W, float w_xx, float w_xy, float w_yy) {
+                                                       int N, int H, int W, float w_xx, float w_xy, float w_yy) {
     __shared__ float red[4];
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    const float *p = pm + (size_t)blockIdx.z * H * W;
     float acc = 0.0f;
-    if (x < W && y < H) {
-        const float c = p[y * W + x];
-        if (x + 2 < W) acc += w_xx * fabsf(p[y * W + x + 2] - 2.0f * p[y * W + x + 1] + c);
-        if (y + 2 < H) acc += w_yy * fabsf(p[(y + 2) * W + x] - 2.0f * p[(y + 1) * W + x] + c);
-        if (x + 1 < W && y + 1 < H)
-            acc += w_xy * fabsf((p[(y + 1) * W + x + 1] - p[(y + 1) * W + x]) - (p[y * W + x + 1] - c));
-    }
+    // grid (ceil(W/32), ceil(H/8), N): one 32x8 patch per workgroup; a (1, 1, 1) grid (deterministic
+    // mode) walks all patches of all maps in a fixed order instead
+    for (int n = blockIdx.z; n < N; n += gridDim.z)
+        for (int y = blockIdx.y * 8 + (threadIdx.x >> 5); y < H; y += gridDim.y * 8)
+            for (int x = blockIdx.x * 32 + (threadIdx.x & 31); x < W; x += gridDim.x * 32) {
+                const float *p = pm + (size_t)n * H * W;
+                const float c = p[y * W + x];
+                if (x + 2 < W) acc += w_xx * fabsf(p[y * W + x + 2] - 2.0f * p[y * W + x + 1] + c);
+                if (y + 2 < H) acc += w_yy * fabsf(p[(y + 2) * W + x] - 2.0f * p[(y + 1) * W + x] + c);
+                if (x + 1 < W && y + 1 < H)
+                    acc += w_xy * fabsf((p[(y + 1) * W + x + 1] - p[(y + 1) * W + x]) - (p[y * W + x + 1] - c));
+            }
     block_atomic_add(acc, loss, red);
 }
 
@@ -335,14 +342,13 @@ __global__ __launch_bounds__(256) void shading_bwd(const float *__restrict__ nor
                                                    float *__restrict__ galbedo,
                                                    float *__restrict__ glight, int P, int Bn, int Ba) {
     __shared__ float red[4];
-    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    const bool ok = p < P;
+    const int b = blockIdx.y;
     const float *l = light + b * 4;
     const float la = l[0] / 2.0f + 0.5f, lb = l[1] / 2.0f + 0.5f;
     const float nrm = sqrtf(l[2] * l[2] + l[3] * l[3] + 1.0f);
     const float dx = l[2] / nrm, dy = l[3] / nrm, dz = 1.0f / nrm;
-    float g_la = 0, g_lb = 0, g_dx = 0, g_dy = 0, g_dz = 0;
-    if (ok) {
+    float s[4] = {0, 0, 0, 0};
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {   // one pass, or all of P in deterministic mode
         const float *n = normal + ((size_t)(Bn == 1 ? 0 : b) * P + p) * 3;
         const float dot = n[0] * dx + n[1] * dy + n[2] * dz;
         const float dif = dot > 0.0f ? dot : 0.0f;
@@ -355,21 +361,21 @@ __global__ __launch_bounds__(256) void shading_bwd(const float *__restrict__ nor
             g_sh += g * (al[(size_t)c * P] / 2.0f + 0.5f) * 2.0f;
             galbedo[(size_t)b * 3 * P + (size_t)c * P + p] = g * sh;  // d/d albedo = 0.5 * sh * 2
         }
-        float g_dif = g_sh * lb + (gdiffuse ? gdiffuse[(size_t)b * P + p] : 0.0f);
-        g_la = g_sh;
-        g_lb = g_sh * dif;
+        const float g_dif = g_sh * lb + (gdiffuse ? gdiffuse[(size_t)b * P + p] : 0.0f);
         const float g_dot = dot > 0.0f ? g_dif : 0.0f;
         float *gn = gnormal + ((size_t)b * P + p) * 3;
         gn[0] = g_dot * dx; gn[1] = g_dot * dy; gn[2] = g_dot * dz;
-        g_dx = g_dot * n[0]; g_dy = g_dot * n[1]; g_dz = g_dot * n[2];
+        const float g_dx = g_dot * n[0], g_dy = g_dot * n[1], g_dz = g_dot * n[2];
+        // direction = (l2, l3, 1) / nrm:  g_l2 = (g_dx - dx * (g . dir)) / nrm, same for l3
+        const float gd_dot = g_dx * dx + g_dy * dy + g_dz * dz;
+        s[0] += g_sh * 0.5f;
+        s[1] += (g_sh * dif) * 0.5f;
+        s[2] += (g_dx - dx * gd_dot) / nrm;
+        s[3] += (g_dy - dy * gd_dot) / nrm;
     }
-    // direction = (l2, l3, 1) / nrm:  g_l2 = (g_dx - dx * (g . dir)) / nrm, same for l3
-    const float gd_dot = g_dx * dx + g_dy * dy + g_dz * dz;
     float *o = glight + b * 4;
-    block_atomic_add(g_la * 0.5f, o + 0, red);
-    block_atomic_add(g_lb * 0.5f, o + 1, red);
-    block_atomic_add((g_dx - dx * gd_dot) / nrm, o + 2, red);
-    block_atomic_add((g_dy - dy * gd_dot) / nrm, o + 3, red);
+#pragma unroll
+    for (int k = 0; k < 4; k++) block_atomic_add(s[k], o + k, red);
 }
 
 static Intr make_intr(const float *K, int H, int W) {
@@ -410,7 +416,7 @@ extern "C" int g2s_warp_verts_bwd(const float *depth, const float *rays, const f
     hipStream_t st = as_stream(stream);
     if (gRt && hipMemsetAsync(gRt, 0, (size_t)B * 12 * sizeof(float), st) != hipSuccess)
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
-    warp_verts_bwd<<<dim3(cdiv(P, 256), B), 256, 0, st>>>(depth, rays, R, gverts, rot_center_depth, gdepth, gRt, P, gRt != nullptr);
+    warp_verts_bwd<<<dim3(deterministic() ? 1 : cdiv(P, 256), B), 256, 0, st>>>(depth, rays, R, gverts, rot_center_depth, gdepth, gRt, P, gRt != nullptr);
     return check_launch("g2s_warp_verts_bwd");
 }
 
@@ -431,7 +437,7 @@ extern "C" int g2s_inv_warp_grid_bwd(const float *depth, const float *rays, cons
     hipStream_t st = as_stream(stream);
     if (gRt && hipMemsetAsync(gRt, 0, (size_t)B * 12 * sizeof(float), st) != hipSuccess)
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
-    inv_warp_grid_bwd<<<dim3(cdiv(H * W, 256), B), 256, 0, st>>>(
+    inv_warp_grid_bwd<<<dim3(deterministic() ? 1 : cdiv(H * W, 256), B), 256, 0, st>>>(
         depth, rays, R, t, rot_center_depth, make_intr(K, H, W), ggrid, gdepth, gRt, H * W, gRt != nullptr);
     return check_launch("g2s_inv_warp_grid_bwd");
 }
@@ -448,7 +454,7 @@ extern "C" int g2s_smooth_loss_fwd(const float *p, float *loss, int N, int H, in
     smooth_weights(N, H, W, wxx, wxy, wyy);
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
-    smooth_loss_fwd<<<dim3(cdiv(W, 32), cdiv(H, 8), N), 256, 0, st>>>(p, loss, H, W, wxx, wxy, wyy);
+    smooth_loss_fwd<<<deterministic() ? dim3(1, 1, 1) : dim3(cdiv(W, 32), cdiv(H, 8), N), 256, 0, st>>>(p, loss, N, H, W, wxx, wxy, wyy);
     return check_launch("g2s_smooth_loss_fwd");
 }
 
@@ -494,6 +500,6 @@ extern "C" int g2s_shading_bwd(const float *normal, const float *light, const fl
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(glight, 0, (size_t)B * 4 * sizeof(float), st) != hipSuccess)
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
-    shading_bwd<<<dim3(cdiv(P, 256), B), 256, 0, st>>>(normal, light, albedo, gdiffuse, gtexture, gnormal, galbedo, glight, P, Bn, Ba);
+    shading_bwd<<<dim3(deterministic() ? 1 : cdiv(P, 256), B), 256, 0, st>>>(normal, light, albedo, gdiffuse, gtexture, gnormal, galbedo, glight, P, Bn, Ba);
     return check_launch("g2s_shading_bwd");
 }

@@ -77,7 +77,8 @@ extern "C" int g2s_weighted_l1_fwd(const float *x, const float *y, const float *
     if (rc) return rc;
     G2S_REQUIRE(num, "num must not be NULL (a ZEROED device float: the sum is accumulated into it)");
     const long total4 = (long)B * C * HW / 4;
-    const int blocks = (int)std::min<long>(cdiv(total4, WL1_THREADS * 4), 2048);
+    // deterministic mode: one workgroup strides over everything, so the sum has one fixed order
+    const int blocks = deterministic() ? 1 : (int)std::min<long>(cdiv(total4, WL1_THREADS * 4), 2048);
     wl1_fwd<<<blocks, WL1_THREADS, 0, as_stream(stream)>>>(x, y, w, num, C, HW / 4, total4);
     return check_launch("g2s_weighted_l1_fwd");
 }

@@ -37,30 +37,37 @@ __global__ __launch_bounds__(64 * SL) void lpips_layer_fwd(const float *__restri
                                                            float *__restrict__ out, int C, int HW) {
     __shared__ float red[SL][64];
     const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int n = blockIdx.y, p = blockIdx.x * 64 + px;
-    const bool ok = p < HW;
-    const float *a = f0 + (size_t)n * C * HW + (ok ? p : 0), *b = f1 + (size_t)n * C * HW + (ok ? p : 0);
-    float s0 = 0.0f, s1 = 0.0f;
+    const int n = blockIdx.y;
+    float total = 0.0f;
+    // one 64-pixel group per workgroup (default), or every group of the image in turn when the grid is
+    // (1, N) — deterministic mode: out[n] then receives one sum with a fixed order
+    for (int p0 = blockIdx.x * 64; p0 < HW; p0 += gridDim.x * 64) {
+        const int p = p0 + px;
+        const bool ok = p < HW;
+        const float *a = f0 + (size_t)n * C * HW + (ok ? p : 0), *b = f1 + (size_t)n * C * HW + (ok ? p : 0);
+        float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll 4
-    for (int c = sl; c < C; c += SL) {
-        const float x = a[(size_t)c * HW], y = b[(size_t)c * HW];
-        s0 += x * x;
-        s1 += y * y;
-    }
-    s0 = slice_sum<SL>(s0, red, sl, px);
-    s1 = slice_sum<SL>(s1, red, sl, px);
-    const float ia = 1.0f / (sqrtf(s0) + LPIPS_EPS), ib = 1.0f / (sqrtf(s1) + LPIPS_EPS);
-    float d = 0.0f;
+        for (int c = sl; c < C; c += SL) {
+            const float x = a[(size_t)c * HW], y = b[(size_t)c * HW];
+            s0 += x * x;
+            s1 += y * y;
+        }
+        s0 = slice_sum<SL>(s0, red, sl, px);
+        s1 = slice_sum<SL>(s1, red, sl, px);
+        const float ia = 1.0f / (sqrtf(s0) + LPIPS_EPS), ib = 1.0f / (sqrtf(s1) + LPIPS_EPS);
+        float d = 0.0f;
 #pragma unroll 4
-    for (int c = sl; c < C; c += SL) {
-        const float df = a[(size_t)c * HW] * ia - b[(size_t)c * HW] * ib;
-        d += w[c] * df * df;
+        for (int c = sl; c < C; c += SL) {
+            const float df = a[(size_t)c * HW] * ia - b[(size_t)c * HW] * ib;
+            d += w[c] * df * df;
+        }
+        d = slice_sum<SL>(ok ? d : 0.0f, red, sl, px);
+        if (sl == 0) {  // one wave: sum over the 64 pixels of this group
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            total += d / (float)HW;
+        }
     }
-    d = slice_sum<SL>(ok ? d : 0.0f, red, sl, px);
-    if (sl == 0) {  // one wave: sum over the 64 pixels of this workgroup
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
-        if (px == 0) unsafeAtomicAdd(out + n, d / (float)HW);
-    }
+    if (sl == 0 && px == 0) unsafeAtomicAdd(out + n, total);
 }
 
 // g0[n,c,p] = gout[n]/HW * ( 2 w_c diff_c / a  -  f0_c / (a^2 n0) * sum_k 2 w_k diff_k f0_k )
@@ -120,8 +127,9 @@ extern "C" int g2s_lpips_layer_fwd(const float *f0, const float *f1, const float
                                    int N, int C, int HW, g2s_stream_t stream) {
     G2S_REQUIRE(f0 && f1 && w && out && N > 0 && C > 0 && HW > 0, "bad argument");
     G2S_REQUIRE(N <= 65535, "N too large for grid.y");
-    if (HW <= 1024) lpips_layer_fwd<16><<<dim3(cdiv(HW, 64), N), 1024, 0, as_stream(stream)>>>(f0, f1, w, out, C, HW);
-    else lpips_layer_fwd<4><<<dim3(cdiv(HW, 64), N), 256, 0, as_stream(stream)>>>(f0, f1, w, out, C, HW);
+    const int groups = deterministic() ? 1 : cdiv(HW, 64);   // deterministic: one workgroup walks the whole image
+    if (HW <= 1024) lpips_layer_fwd<16><<<dim3(groups, N), 1024, 0, as_stream(stream)>>>(f0, f1, w, out, C, HW);
+    else lpips_layer_fwd<4><<<dim3(groups, N), 256, 0, as_stream(stream)>>>(f0, f1, w, out, C, HW);
     return check_launch("g2s_lpips_layer_fwd");
 }
 

@@ -459,13 +459,32 @@ struct BwdParams {
     int B, N, F, S, is, ssaa;
     Cam cam;
     float *gacc;  // [B, N, 3]: first (g_u, g_v, g_z) of the projected vertices, then in place xyz
+    long long *gfix;  // deterministic mode: the same sums as 2^-40 fixed point (integer adds commute)
 };
+
+// Deterministic mode accumulates in 64-bit fixed point (LDS and global integer atomics): the sums no
+// longer depend on the order the waves arrive in.  Resolution 2^-40 ~ 9e-13, range +-8.4e6 per
+// component; a non-finite contribution is not representable and is dropped.
+constexpr float FIX_SCALE = 1099511627776.0f;  // 2^40
+__device__ __forceinline__ long long to_fix(float v) { return __float2ll_rn(v * FIX_SCALE); }
+__device__ __forceinline__ float from_fix(long long v) { return (float)((double)v * (1.0 / 1099511627776.0)); }
+__device__ __forceinline__ void acc_add(float *dst, float v) { unsafeAtomicAdd(dst, v); }
+__device__ __forceinline__ void acc_add(long long *dst, float v) {
+    atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)to_fix(v));
+}
+__device__ __forceinline__ void acc_add(long long *dst, long long v) {
+    atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)v);
+}
+__device__ __forceinline__ void lds_add(float *dst, float v) { atomicAdd(dst, v); }
+__device__ __forceinline__ void lds_add(long long *dst, float v) { acc_add(dst, v); }
 
 // One wave per 8x8-sample tile (4 tiles per workgroup).  The 2x2 super-samples of a pixel mostly hit
 // the same face: before the atomics, x- and then y-neighbours with the same winning face merge
 // their nine partial gradients through shuffles, so a face's vertices receive one atomic triple per
 // merged group instead of one per sample.
+template <typename ACC>   // float (default) or long long (deterministic mode, fixed point)
 __global__ __launch_bounds__(256) void raster_bwd_samples(BwdParams p) {
+    ACC *const gout = sizeof(ACC) == 8 ? reinterpret_cast<ACC *>(p.gfix) : reinterpret_cast<ACC *>(p.gacc);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tiles_side = (p.is + TILE - 1) / TILE;
     const int tile = blockIdx.x * 4 + wave, b = blockIdx.y;
@@ -528,10 +547,10 @@ __global__ __launch_bounds__(256) void raster_bwd_samples(BwdParams p) {
     // memory once (three float atomics) instead of once per merged sample group and corner
     constexpr int HS = 128;
     __shared__ int hkey[4][HS];
-    __shared__ float hval[4][HS][3];
+    __shared__ ACC hval[4][HS][3];
     for (int i2 = lane; i2 < HS; i2 += 64) {
         hkey[wave][i2] = -1;
-        hval[wave][i2][0] = hval[wave][i2][1] = hval[wave][i2][2] = 0.0f;
+        hval[wave][i2][0] = hval[wave][i2][1] = hval[wave][i2][2] = (ACC)0;
     }
     __builtin_amdgcn_wave_barrier();
     if (fn >= 0) {
@@ -541,18 +560,18 @@ __global__ __launch_bounds__(256) void raster_bwd_samples(BwdParams p) {
             for (int probe = 0; probe < 16 && !done; probe++) {
                 const int old = atomicCAS(&hkey[wave][slot], -1, v[k]);
                 if (old == -1 || old == v[k]) {
-                    atomicAdd(&hval[wave][slot][0], acc[3 * k]);
-                    atomicAdd(&hval[wave][slot][1], acc[3 * k + 1]);
-                    atomicAdd(&hval[wave][slot][2], acc[3 * k + 2]);
+                    lds_add(&hval[wave][slot][0], acc[3 * k]);
+                    lds_add(&hval[wave][slot][1], acc[3 * k + 1]);
+                    lds_add(&hval[wave][slot][2], acc[3 * k + 2]);
                     done = true;
                 }
                 slot = (slot + 1) & (HS - 1);
             }
             if (!done) {  // crowded table (many distinct vertices in one tile): straight to memory
-                float *dst = p.gacc + ((size_t)b * p.N + v[k]) * 3;
-                unsafeAtomicAdd(dst + 0, acc[3 * k]);
-                unsafeAtomicAdd(dst + 1, acc[3 * k + 1]);
-                unsafeAtomicAdd(dst + 2, acc[3 * k + 2]);
+                ACC *dst = gout + ((size_t)b * p.N + v[k]) * 3;
+                acc_add(dst + 0, acc[3 * k]);
+                acc_add(dst + 1, acc[3 * k + 1]);
+                acc_add(dst + 2, acc[3 * k + 2]);
             }
         }
     }
@@ -560,10 +579,10 @@ __global__ __launch_bounds__(256) void raster_bwd_samples(BwdParams p) {
     for (int i2 = lane; i2 < HS; i2 += 64) {
         const int key = hkey[wave][i2];
         if (key >= 0) {
-            float *dst = p.gacc + ((size_t)b * p.N + key) * 3;
-            unsafeAtomicAdd(dst + 0, hval[wave][i2][0]);
-            unsafeAtomicAdd(dst + 1, hval[wave][i2][1]);
-            unsafeAtomicAdd(dst + 2, hval[wave][i2][2]);
+            ACC *dst = gout + ((size_t)b * p.N + key) * 3;
+            acc_add(dst + 0, hval[wave][i2][0]);
+            acc_add(dst + 1, hval[wave][i2][1]);
+            acc_add(dst + 2, hval[wave][i2][2]);
         }
     }
 }
@@ -574,7 +593,12 @@ __global__ __launch_bounds__(256) void raster_bwd_project(BwdParams p) {
     const float *q = p.verts + i * 3;
     float *g = p.gacc + i * 3;
     float gx, gy, gz;
-    project_backward(q[0], q[1], q[2], p.cam, g[0], g[1], g[2], gx, gy, gz);
+    if (p.gfix) {
+        const long long *f = p.gfix + i * 3;
+        project_backward(q[0], q[1], q[2], p.cam, from_fix(f[0]), from_fix(f[1]), from_fix(f[2]), gx, gy, gz);
+    } else {
+        project_backward(q[0], q[1], q[2], p.cam, g[0], g[1], g[2], gx, gy, gz);
+    }
     g[0] = gx;
     g[1] = gy;
     g[2] = gz;
@@ -679,11 +703,16 @@ extern "C" int g2s_raster_depth_fwd(const float *verts, const int32_t *faces, in
     return check_launch("g2s_raster_depth_fwd");
 }
 
-extern "C" int g2s_raster_depth_bwd(const float *verts, const int32_t *faces,
-                                    const float *grad_depth, const int32_t *face_idx,
-                                    const float *bary, int B, int n_verts, int n_faces, int S,
-                                    const float *K, float orig_size, int ssaa, float *grad_verts,
-                                    g2s_stream_t stream) {
+extern "C" size_t g2s_raster_bwd_workspace_bytes(int B, int n_verts) {
+    if (B <= 0 || n_verts <= 0) return 0;
+    return (size_t)B * n_verts * 3 * sizeof(long long) + 256;
+}
+
+extern "C" int g2s_raster_depth_bwd_ex(const float *verts, const int32_t *faces,
+                                       const float *grad_depth, const int32_t *face_idx,
+                                       const float *bary, int B, int n_verts, int n_faces, int S,
+                                       const float *K, float orig_size, int ssaa, float *grad_verts,
+                                       void *workspace, size_t workspace_bytes, g2s_stream_t stream) {
     G2S_REQUIRE(verts && grad_depth && face_idx && bary && grad_verts, "NULL pointer argument");
     int rc = check_shape(faces, B, n_verts, n_faces, S, ssaa);
     if (rc) return rc;
@@ -703,10 +732,31 @@ extern "C" int g2s_raster_depth_bwd(const float *verts, const int32_t *faces,
     p.is = S * ssaa;
     p.gacc = grad_verts;
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(grad_verts, 0, (size_t)B * n_verts * 3 * sizeof(float), st) != hipSuccess)
-        return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(grad_verts) failed");
     const int bw_tiles = cdiv(p.is, TILE) * cdiv(p.is, TILE);
-    raster_bwd_samples<<<dim3(cdiv(bw_tiles, 4), B), 256, 0, st>>>(p);
+    if (deterministic()) {
+        // float atomics would make the vertex sums depend on the order the tiles finish in
+        if (!workspace || workspace_bytes < g2s_raster_bwd_workspace_bytes(B, n_verts))
+            return fail(G2S_ERR_WORKSPACE, "deterministic mode: the backward needs its fixed-point workspace "
+                        "(g2s_raster_bwd_workspace_bytes = %zu bytes, got %zu)",
+                        g2s_raster_bwd_workspace_bytes(B, n_verts), workspace ? workspace_bytes : (size_t)0);
+        p.gfix = reinterpret_cast<long long *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+        if (hipMemsetAsync(p.gfix, 0, (size_t)B * n_verts * 3 * sizeof(long long), st) != hipSuccess)
+            return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
+        raster_bwd_samples<long long><<<dim3(cdiv(bw_tiles, 4), B), 256, 0, st>>>(p);
+    } else {
+        if (hipMemsetAsync(grad_verts, 0, (size_t)B * n_verts * 3 * sizeof(float), st) != hipSuccess)
+            return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(grad_verts) failed");
+        raster_bwd_samples<float><<<dim3(cdiv(bw_tiles, 4), B), 256, 0, st>>>(p);
+    }
     raster_bwd_project<<<cdiv((long)B * n_verts, 256), 256, 0, st>>>(p);
     return check_launch("g2s_raster_depth_bwd");
+}
+
+extern "C" int g2s_raster_depth_bwd(const float *verts, const int32_t *faces,
+                                    const float *grad_depth, const int32_t *face_idx,
+                                    const float *bary, int B, int n_verts, int n_faces, int S,
+                                    const float *K, float orig_size, int ssaa, float *grad_verts,
+                                    g2s_stream_t stream) {
+    return g2s_raster_depth_bwd_ex(verts, faces, grad_depth, face_idx, bary, B, n_verts, n_faces, S, K,
+                                   orig_size, ssaa, grad_verts, nullptr, 0, stream);
 }

@@ -19,12 +19,17 @@ SIGNATURES = {
     "g2s_abi_version": (_i, []),
     "g2s_last_error": (C.c_char_p, []),
     "g2s_clamp": (_i, [_p, _p, _p, _i64, _f, _f, _i, _p]),
+    "g2s_grid_sample_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
+    "g2s_grid_sample_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "g2s_grid_sample_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),
     "g2s_set_deterministic": (_i, [_i]),
     "g2s_get_deterministic": (_i, []),
     "g2s_raster_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "g2s_raster_tune": (_i, [_i]),
     "g2s_raster_depth_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p, _f, _i, _i, _f, _f, _p, _p, _p, _p, _sz, _p]),
     "g2s_raster_depth_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _f, _i, _p, _p]),
+    "g2s_raster_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "g2s_raster_depth_bwd_ex": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _f, _i, _p, _p, _sz, _p]),
     "g2s_raster_rgb_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _f, _p, _p]),
     "g2s_fused_bias_act": (_i, [_p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _f, _f, _i, _p]),
     "g2s_maxpool2x2_fwd": (_i, [_p, _p, _i64, _i, _i, _p]),

@@ -30,7 +30,7 @@ import torch.nn.functional as F
 from torch.distributions.multivariate_normal import MultivariateNormal
 
 from . import networks, utils, zeropool
-from .op import clamp
+from .op import grid_sample
 from .losses import DiscriminatorLoss, PhotometricLoss, SmoothLoss
 from .lpips import PerceptualLoss
 from .renderer import Renderer
@@ -297,7 +297,7 @@ class GAN2Shape(nn.Module):
         margin = (self.max_depth - self.min_depth) / 2
         # invalid border pixels have been clamped at max_depth+margin
         recon_im_mask = (recon_depth < self.max_depth + margin).float().unsqueeze(1).detach()
-        recon_im = clamp(F.grid_sample(texture, grid_2d_from_canon, mode='bilinear', align_corners=True), -1, 1)
+        recon_im = grid_sample(texture, grid_2d_from_canon, -1, 1)   # F.grid_sample(..).clamp(-1, 1), one launch
         if eval:
             return recon_im, recon_depth
 
@@ -454,7 +454,7 @@ class GAN2Shape(nn.Module):
         grid_2d_from_canon = self.renderer.get_inv_warped_2d_grid(recon_depth)
         margin = (self.max_depth - self.min_depth) / 2
         recon_im_mask = (recon_depth < self.max_depth + margin).float().unsqueeze(1).detach() * masks
-        recon_im = clamp(F.grid_sample(texture, grid_2d_from_canon, mode='bilinear', align_corners=True), -1, 1)
+        recon_im = grid_sample(texture, grid_2d_from_canon, -1, 1)   # F.grid_sample(..).clamp(-1, 1), one launch
 
         recon_b, mask_b = self._head(recon_im, b), self._head(recon_im_mask, b)
         loss_l1_im = self.photometric_loss(recon_b, projected_samples, mask=mask_b)

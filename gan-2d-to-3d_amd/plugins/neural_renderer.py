@@ -91,9 +91,13 @@ class RenderDepthFunction(Function):
         gv = torch.empty_like(verts)
         L = _lib.load()
         Kc = (_lib.C.c_float * 9)(*K)
-        _lib.check(L.g2s_raster_depth_bwd(_lib.ptr(verts), _lib.ptr(faces), _lib.ptr(g),
-                                          _lib.ptr(fidx), _lib.ptr(bary), B, N, F, S, Kc, orig_size,
-                                          ssaa, _lib.ptr(gv), _lib.stream()))
+        ws = None       # deterministic mode sums in fixed point in a scratch buffer (include/g2s.h)
+        if L.g2s_get_deterministic():
+            ws = torch.empty(L.g2s_raster_bwd_workspace_bytes(B, N), dtype=torch.uint8, device=verts.device)
+        _lib.check(L.g2s_raster_depth_bwd_ex(_lib.ptr(verts), _lib.ptr(faces), _lib.ptr(g),
+                                             _lib.ptr(fidx), _lib.ptr(bary), B, N, F, S, Kc, orig_size,
+                                             ssaa, _lib.ptr(gv), _lib.ptr(ws), ws.numel() if ws is not None else 0,
+                                             _lib.stream()))
         return gv, None, None, None, None, None, None, None, None
 
 

@@ -98,6 +98,20 @@ int g2s_raster_depth_bwd(const float *verts, const int32_t *faces, const float *
                          int n_faces, int S, const float *K, float orig_size, int ssaa,
                          float *grad_verts, g2s_stream_t stream);
 
+/* The same with the scratch deterministic mode needs (g2s_set_deterministic): the per-vertex sums are
+ * then accumulated as 2^-40 fixed point with 64-bit integer atomics in `workspace`
+ * (>= g2s_raster_bwd_workspace_bytes(B, n_verts) bytes of device memory), whose result does not depend
+ * on the order the tiles arrive in — the gradient is bit-identical from run to run — and converted to
+ * grad_verts at the end (range +-8.4e6 per component, resolution 9e-13; non-finite contributions are
+ * dropped).  In deterministic mode a NULL / short workspace is G2S_ERR_WORKSPACE — also through
+ * g2s_raster_depth_bwd, which passes none; otherwise the workspace is ignored. */
+size_t g2s_raster_bwd_workspace_bytes(int B, int n_verts);
+int g2s_raster_depth_bwd_ex(const float *verts, const int32_t *faces, const float *grad_depth,
+                            const int32_t *face_idx, const float *bary, int B, int n_verts,
+                            int n_faces, int S, const float *K, float orig_size, int ssaa,
+                            float *grad_verts, void *workspace, size_t workspace_bytes,
+                            g2s_stream_t stream);
+
 /* Texture path: nr.Renderer.render_rgb(vertices, faces, textures [B,F,ts,ts,ts,C]) as the reference's
  * visualisation helpers call it (GAN2Shape/renderer/renderer.py:196,230,248,272,275).  Forward only.
  * Second pass over the maps g2s_raster_depth_fwd saves (run it with the constructor's near / far,
@@ -136,6 +150,23 @@ int g2s_maxpool2x2_bwd(const float *x, const float *gy, float *gx, int64_t plane
  * (out + skip) / sqrt(2) (model.py:693-697).  a, b, y [n] f32; b and bias [C] may be NULL. */
 int g2s_add_bias_scale(const float *a, const float *b, const float *bias, float *y, int64_t n, int64_t hw, int C,
                        float scale, g2s_stream_t stream);
+
+/* The reconstruction warp: torch.nn.functional.grid_sample(x, grid, mode='bilinear', padding_mode='zeros',
+ * align_corners=True) as GAN2Shape/model.py:147,267 calls it, optionally followed by .clamp(lo, hi)
+ * (model.py:150,270) in the same pass (clamp = 1).  ATen's arithmetic (corner order nw, ne, sw, se).
+ *   x [B, C, IH, IW], grid [B, H, W, 2] (x then y in [-1, 1]), y / gy [B, C, H, W], all f32.
+ * Backward: gx [B, C, IH, IW] (zero-filled by the callee, then scattered) and ggrid [B, H, W, 2]; either
+ * may be NULL.  With clamp = 1 the gradient passes where lo <= sample <= hi (torch's rule), the sample
+ * being recomputed.  The scatter uses float atomics; in deterministic mode (g2s_set_deterministic) it
+ * accumulates 2^-40 fixed point with 64-bit integer atomics in `workspace`
+ * (>= g2s_grid_sample_bwd_workspace_bytes) and converts at the end — bit-identical from run to run, which
+ * ATen's grid_sampler_2d_backward cannot offer; there a NULL / short workspace is G2S_ERR_WORKSPACE. */
+int g2s_grid_sample_fwd(const float *x, const float *grid, float *y, int B, int C, int IH, int IW, int H, int W,
+                        int clamp, float lo, float hi, g2s_stream_t stream);
+size_t g2s_grid_sample_bwd_workspace_bytes(int B, int C, int IH, int IW);
+int g2s_grid_sample_bwd(const float *gy, const float *x, const float *grid, float *gx, float *ggrid, int B, int C,
+                        int IH, int IW, int H, int W, int clamp, float lo, float hi, void *workspace,
+                        size_t workspace_bytes, g2s_stream_t stream);
 
 /* torch.clamp(x, lo, hi) of the step's image / depth clamps (GAN2Shape/model.py:150,270, renderer.py:123-124)
  * and its backward as ONE launch each (autograd's ClampBackward is five: ge, le, logical_and, where, fill).

@@ -218,3 +218,186 @@ def test_discriminator_loss_one_node_equals_op_by_op(masked):
     assert float((a - b).norm() / b.norm()) <= 2e-3
     assert float((err > 5e-3 * b.abs().max()).double().mean()) <= 1e-3
     assert float(err.max()) <= 5e-2 * float(b.abs().max())
+
+
+# ----------------------------------------------------------------------- reconstruction warp (grid_sample.hip)
+def _warp_inputs(B, C, IH, IW, H, W, seed, spill=1.15):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(B, C, IH, IW, generator=g) * 0.9).cuda()
+    # a smooth warp plus jitter; `spill` > 1 pushes some samples outside the texture (zero padding)
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    base = torch.stack([xs, ys], -1)[None].repeat(B, 1, 1, 1) * spill
+    grid = (base + 0.05 * torch.randn(B, H, W, 2, generator=g)).cuda()
+    gy = torch.randn(B, C, H, W, generator=g).cuda()
+    return x, grid, gy
+
+
+@pytest.mark.parametrize("B,C,IH,IW,H,W,bounds", [(8, 3, 128, 128, 128, 128, (-1.0, 1.0)), (2, 3, 64, 64, 64, 64, None),
+                                                  (3, 1, 17, 23, 40, 31, (-0.3, 0.4)), (1, 5, 32, 32, 8, 8, None)])
+def test_grid_sample_matches_torch(L, B, C, IH, IW, H, W, bounds):
+    """g2s_grid_sample_* against F.grid_sample(.., 'bilinear', align_corners=True)[.clamp(lo, hi)] — the
+    reference's own calls (GAN2Shape/model.py:147-150, 267-270) — forward, texture gradient and grid
+    gradient, including samples that fall off the texture and values on either side of the clamp."""
+    import torch.nn.functional as F
+    from gan2shape_amd.op import grid_sample
+    x, grid, gy = _warp_inputs(B, C, IH, IW, H, W, 5)
+    outs = []
+    for mine in (True, False):
+        xx, gg = x.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+        if mine:
+            y = grid_sample(xx, gg, *(bounds or (None, None)))
+        else:
+            y = F.grid_sample(xx, gg, mode="bilinear", align_corners=True)
+            y = y if bounds is None else y.clamp(*bounds)
+        y.backward(gy)
+        outs.append((y.detach(), xx.grad, gg.grad))
+    (y, gx, ggr), (y0, gx0, ggr0) = outs
+    assert float((y - y0).abs().max()) <= 2e-6 * max(1.0, float(y0.abs().max()))
+    if bounds is not None:
+        assert float((y0 == bounds[0]).float().mean()) > 0.01 and float((y0 == bounds[1]).float().mean()) > 0.01
+    assert float((y0 == 0).float().mean()) > 0.005                       # some samples are off the texture
+    # a clamp decision can differ where the sample is within one rounding of a bound: bounded count
+    for a, b, name in ((gx, gx0, "gx"), (ggr, ggr0, "ggrid")):
+        e = (a - b).abs()
+        scale = float(b.abs().max())
+        loose = int((e > 2e-5 * scale).sum())
+        assert loose <= (4 * C if bounds is not None else 0), (name, loose, float(e.max()), scale)
+        assert float((a - b).norm() / b.norm()) <= 2e-4, name
+
+
+def test_grid_sample_gradient_is_bitwise_reproducible_in_deterministic_mode(L):
+    from gan2shape_amd import lib
+    from gan2shape_amd.op import grid_sample
+    x, grid, gy = _warp_inputs(8, 3, 128, 128, 128, 128, 6)
+
+    def grads():
+        xx, gg = x.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+        grid_sample(xx, gg, -1.0, 1.0).backward(gy)
+        return xx.grad, gg.grad
+    ref = grads()
+    lib.set_deterministic(True)
+    try:
+        runs = [grads() for _ in range(4)]
+    finally:
+        lib.set_deterministic(False)
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1])
+    # fixed point at 2^-40 against the float-atomic sum: fp32 rounding apart
+    assert float((runs[0][0] - ref[0]).abs().max()) <= 2e-6 * float(ref[0].abs().max())
+    assert torch.equal(runs[0][1], ref[1])                                # the grid gradient has no scatter
+
+
+def test_raster_backward_is_bitwise_reproducible_in_deterministic_mode(L):
+    """g2s_raster_depth_bwd_ex with its fixed-point workspace: identical vertex gradients from run to run
+    (the float-atomic default differs in the last bits), equal to the default up to fp32 rounding; without
+    the workspace deterministic mode refuses (G2S_ERR_WORKSPACE)."""
+    from gan2shape_amd import lib
+    from gan2shape_amd.plugins import neural_renderer as nr
+    S, B = 64, 4
+    g = torch.Generator().manual_seed(9)
+    ys, xs = torch.meshgrid(torch.linspace(-0.3, 0.3, S), torch.linspace(-0.3, 0.3, S), indexing="ij")
+    z = 1.0 + 0.05 * torch.randn(B, S, S, generator=g).cumsum(1).cumsum(2) / S
+    verts = torch.stack([xs[None] * z, ys[None] * z, z], -1).reshape(B, S * S, 3).cuda()
+    K = [2.0 * S, 0.0, S / 2.0, 0.0, 2.0 * S, S / 2.0, 0.0, 0.0, 1.0]
+    gd = torch.randn(B, S, S, generator=g).cuda()
+
+    def grad():
+        v = verts.clone().requires_grad_(True)
+        d = nr.RenderDepthFunction.apply(v, None, K, float(S), S, True, True, 0.1, 100.0)
+        d.backward(gd)
+        return v.grad
+    ref = grad()
+    assert float(ref.abs().max()) > 0
+    lib.set_deterministic(True)
+    try:
+        runs = [grad() for _ in range(4)]
+        v = verts.clone()
+        fidx = torch.zeros(B, 2 * S, 2 * S, dtype=torch.int32, device="cuda")
+        bary = torch.zeros(B, 2 * S, 2 * S, 3, device="cuda")
+        Kc = (lib.C.c_float * 9)(*K)
+        rc = L.g2s_raster_depth_bwd(lib.ptr(v), None, lib.ptr(gd), lib.ptr(fidx), lib.ptr(bary), B, S * S,
+                                    2 * (S - 1) * (S - 1), S, Kc, float(S), 2, lib.ptr(torch.empty_like(v)), lib.stream())
+        assert rc == -3 and b"workspace" in L.g2s_last_error()
+    finally:
+        lib.set_deterministic(False)
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0])
+    assert float((runs[0] - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_training_steps_are_bitwise_reproducible_in_deterministic_mode():
+    """The switch the reference lacks: with g2s_set_deterministic(1) every step kind returns the same loss
+    and the same parameter gradients, bit for bit, when run twice from the same state (two Adam updates
+    then land on identical parameters).  The default mode is checked to differ only at fp32 rounding."""
+    import bench
+    from gan2shape_amd import lib
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import Trainer
+    torch.manual_seed(0)
+    t = Trainer(GAN2Shape, bench.face_config(n_proj=4), device="cuda")
+    m = t.model
+    image, latent = bench.synthetic_sample(m, 99, torch.device("cuda"))
+
+    def grads_of(step, collected):
+        for p in m.parameters():
+            p.grad = None
+        torch.manual_seed(5)
+        loss, out = getattr(m, f"forward_step{step}")(image, latent, collected, n_proj_samples=4)
+        loss.backward()
+        return float(loss.detach()), [p.grad.clone() for p in m.parameters() if p.grad is not None], out
+
+    for det in (True, False):
+        lib.set_deterministic(det)
+        try:
+            collected = None
+            for step in (1, 2, 3):
+                l1, g1, out = grads_of(step, collected)
+                l2, g2, _ = grads_of(step, collected)
+                assert len(g1) == len(g2) and len(g1) > 0
+                if det:
+                    assert l1 == l2, (step, l1, l2)
+                    differing = sum(int(not torch.equal(a, b)) for a, b in zip(g1, g2))
+                    assert differing == 0, (step, differing, len(g1))
+                else:
+                    worst = max(float((a - b).norm() / (a.norm() + 1e-30)) for a, b in zip(g1, g2))
+                    assert abs(l1 - l2) <= 1e-5 * abs(l1) and worst <= 1e-2, (step, l1, l2, worst)
+                collected = out
+        finally:
+            lib.set_deterministic(False)
+
+
+def test_graph_replayed_training_run_is_bitwise_reproducible_in_deterministic_mode():
+    """Two whole runs — build, capture, replay 1 1 2 2 3 3 — from the same seed end on identical
+    parameters in every trained net (the Adam updates included), bit for bit."""
+    import bench
+    from gan2shape_amd import lib
+    from gan2shape_amd.graphs import GraphedSteps
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import Trainer
+
+    def run():
+        torch.manual_seed(0)
+        t = Trainer(GAN2Shape, bench.face_config(n_proj=4), device="cuda", capturable=True)
+        image, latent = bench.synthetic_sample(t.model, 77, torch.device("cuda"))
+        g = GraphedSteps(trainer=t, image=image, latent=latent, warmup=2)
+        for kind in (1, 2, 3):
+            g.capture(kind)
+        torch.manual_seed(11)
+        losses = [float(g.run(kind)) for kind in (1, 1, 2, 2, 3, 3)]
+        torch.cuda.synchronize()
+        params = {f"{n}.{k}": p.detach().clone() for n in t.model.NETS
+                  for k, p in getattr(t.model, n + "_net").named_parameters()}
+        return losses, params
+
+    dev_ = torch.device("cuda")
+    torch.cuda.set_stream(torch.cuda.Stream(dev_))     # captures need a non-default stream
+    lib.set_deterministic(True)
+    try:
+        la, pa = run()
+        lb, pb = run()
+    finally:
+        lib.set_deterministic(False)
+        torch.cuda.set_stream(torch.cuda.default_stream(dev_))
+    assert la == lb, (la, lb)
+    differing = [k for k in pa if not torch.equal(pa[k], pb[k])]
+    assert not differing, (len(differing), len(pa), differing[:5])
