@@ -409,6 +409,9 @@ def main():
                          "config 5 (256x256, fp16-operand MFMA), reported on its own line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graphs)")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="analysis only: g2s_set_deterministic(1) — bit-reproducible iterations (fixed-order "
+                         "partitions, fixed-point scatters); the default line is measured without it")
     ap.add_argument("--only", type=int, default=0, choices=[0, 1, 2, 3],
                     help="analysis only: time a single step kind instead of the 7:7:6 mix")
     args = ap.parse_args()
@@ -438,6 +441,8 @@ def main():
 
     torch.manual_seed(0)  # identical random-init weights on every rank
     cfg = face_config(args.n_proj, args.workload)
+    if args.deterministic:
+        cfg["deterministic"] = True
     trainer = Trainer(GAN2Shape, cfg, device=device, capturable=not args.eager)
     image, latent = synthetic_sample(trainer.model, 1234 + rank, device)
     torch.manual_seed(1234 + rank)
@@ -595,12 +600,15 @@ def main():
                        "mfma_operands": cfg['mfma_operands'], "prior": cfg['prior_name'],
                        "step_mix": "7:7:6 (step1:step2:step3, main.py:148 stage 0)" if not args.only
                        else f"step{args.only} only (analysis run, not the BASELINE metric)",
-                       "images_per_rank": 1, "sharding": "one image per rank, no collective"},
+                       "images_per_rank": 1, "sharding": "one image per rank, no collective",
+                       **({"deterministic": "g2s_set_deterministic(1): bit-reproducible iterations (analysis run, "
+                                            "not the BASELINE metric)"} if args.deterministic else {})},
             "ms_per_step_kind": {f"step{k}": v for k, v in kind_ms.items()},
             "launch_mode": "eager" if args.eager else "hipGraph replay (one graph per step kind)",
             "final_loss": final_loss,
             "roofline": roofline,
-            "roofline_other": roofline_other(device) if world == 1 and args.workload == "face128_n8" else None,
+            "roofline_other": roofline_other(device) if world == 1 and args.workload == "face128_n8"
+            and not args.deterministic else None,
         }
         if args.workload != "face128_n8":
             out["roofline"]["peak_note"] = ("fp16-operand launches are priced against the fp32 matrix peak here; "
