@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void demod_bwd(const float *__restrict__ wsq,
                                                  const float *__restrict__ s,
                                                  const float *__restrict__ demod,
                                                  const float *__restrict__ gd,
+                                                 const float *__restrict__ gs_add,
                                                  float *__restrict__ gs, int B, int Cin, int Cout) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -98,8 +99,10 @@ __global__ __launch_bounds__(256) void demod_bwd(const float *__restrict__ wsq,
     }
     red[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && i < Cin)
-        gs[b * Cin + i] = -s[b * Cin + i] * (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    if (wave == 0 && i < Cin) {
+        const float g = -s[b * Cin + i] * (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+        gs[b * Cin + i] = gs_add ? gs_add[b * Cin + i] + g : g;
+    }
 }
 
 }  // namespace g2s
@@ -127,6 +130,13 @@ extern "C" int g2s_demod_fwd(const float *wsq, const float *s, float *demod, int
 extern "C" int g2s_demod_bwd(const float *wsq, const float *s, const float *demod, const float *gd,
                              float *gs, int B, int Cin, int Cout, g2s_stream_t stream) {
     G2S_REQUIRE(wsq && s && demod && gd && gs && B > 0 && Cin > 0 && Cout > 0, "bad argument");
-    demod_bwd<<<dim3(cdiv(Cin, 64), B), 256, 0, as_stream(stream)>>>(wsq, s, demod, gd, gs, B, Cin, Cout);
+    demod_bwd<<<dim3(cdiv(Cin, 64), B), 256, 0, as_stream(stream)>>>(wsq, s, demod, gd, nullptr, gs, B, Cin, Cout);
     return check_launch("g2s_demod_bwd");
+}
+
+extern "C" int g2s_demod_bwd_add(const float *wsq, const float *s, const float *demod, const float *gd,
+                                 const float *gs_add, float *gs, int B, int Cin, int Cout, g2s_stream_t stream) {
+    G2S_REQUIRE(wsq && s && demod && gd && gs && B > 0 && Cin > 0 && Cout > 0, "bad argument");
+    demod_bwd<<<dim3(cdiv(Cin, 64), B), 256, 0, as_stream(stream)>>>(wsq, s, demod, gd, gs_add, gs, B, Cin, Cout);
+    return check_launch("g2s_demod_bwd_add");
 }

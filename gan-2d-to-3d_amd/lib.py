@@ -56,6 +56,7 @@ SIGNATURES = {
     "g2s_rows_dot_scale": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "g2s_demod_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
     "g2s_demod_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "g2s_demod_bwd_add": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_lpips_layer_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_lpips_layer_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_lpips_layer_bwd_ex": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p]),

@@ -290,6 +290,52 @@ class ModConvFunction(Function):
         return gx, gw, gs, gd, None
 
 
+class ModConvDemodFunction(Function):
+    """demodulation + modulated convolution as ONE autograd node (the style then receives one gradient:
+    the demodulation path's, with the convolution's in_scale path added inside g2s_demod_bwd_add —
+    as two nodes autograd spends an accumulation launch per layer).  wsq: constant (frozen generator)."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, wsq, eps, mode):
+        s, wsq = s.contiguous(), wsq.contiguous()
+        B, Cin = s.shape
+        demod = torch.empty((B, wsq.shape[0]), dtype=torch.float32, device=s.device)
+        L = _lib.load()
+        _lib.check(L.g2s_demod_fwd(_lib.ptr(wsq), _lib.ptr(s), _lib.ptr(demod), B, Cin, wsq.shape[0], float(eps),
+                                   _lib.stream()))
+        y = modconv_raw(x, w, s, demod, mode, 0)
+        ctx.mode = mode
+        ctx.save_for_backward(x, w, s, wsq, demod, y if ctx.needs_input_grad[2] else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, s, wsq, demod, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        need_x, need_w, need_s = ctx.needs_input_grad[:3]
+        gx = gw = gs = None
+        if need_x or need_s:
+            gxs = modconv_raw(gy, w, demod, None, ctx.mode, 1)  # gradient w.r.t. (s * x)
+            # one pass over (x, gxs): gs = sum_hw x * gxs and gx = gxs * s
+            gx, gs = rows_dot_scale(x, gxs, s, None, want_out=need_x, want_dot=need_s)
+        if need_s:
+            _, gd = rows_dot_scale(gy, y, None, demod, want_out=False, want_dot=True)
+            B, Cin = s.shape
+            _lib.check(_lib.load().g2s_demod_bwd_add(_lib.ptr(wsq), _lib.ptr(s), _lib.ptr(demod), _lib.ptr(gd),
+                                                     _lib.ptr(gs), _lib.ptr(gs), B, Cin, wsq.shape[0], _lib.stream()))
+        if need_w:
+            gw = _weight_grad(x, w, s, demod, gy, ctx.mode)
+        return gx, gw, gs, None, None, None
+
+
+def modconv_demod(x, w, s, wsq, eps=1e-8, mode=PLAIN):
+    """modconv(x, w, s, demodulation(s, wsq, eps), mode); one node when wsq is a constant."""
+    if wsq.requires_grad:
+        return modconv(x, w, s, demodulation(s, wsq, eps), mode)
+    _lib.require_cuda(s, wsq)
+    return ModConvDemodFunction.apply(x, w, s, wsq, eps, mode)
+
+
 def _weight_grad(x, w, s, demod, gy, mode):
     """Off the hot path (G is frozen in GAN2Shape): weight gradient through torch's conv."""
     import torch.nn.functional as F

@@ -153,6 +153,7 @@ class GAN2Shape(nn.Module):
         self._depth_border = None
         self._centers = None
         self.batch_mean = None  # see get_clamped_depth
+        self._relight_consts = None
         # run the independent D / A / V / L nets as concurrent stream branches (see _fork); off by
         # default: measured slower on MI355X (step 1: 3.45 -> 5.66 ms) — a forked HIP graph pays
         # more for its cross-queue joins than the overlapped launch latencies give back
@@ -380,16 +381,27 @@ class GAN2Shape(nn.Module):
         rand_light_dxy[:, 1].uniform_(y_min, y_max)
         if _draws is not None:
             rand_light_dxy = _draws[0].to(dev)
-        rand_light_d = torch.cat([rand_light_dxy, torch.ones(n_images, 1, device=dev)], 1)
-        rand_light_d = rand_light_d / ((rand_light_d ** 2).sum(1, keepdim=True)) ** 0.5
-        rand_diffuse_shading = (normal[0, None] * rand_light_d.view(-1, 1, 1, 3)).sum(3)\
-            .clamp(min=0).unsqueeze(1)
         rand = torch.empty(n_images, 1, 1, 1, device=dev).uniform_(diffuse_min, diffuse_max)
         if _draws is not None:
             rand = _draws[1].to(dev)
-        rand_diffuse = (light_b[0, None].view(-1, 1, 1, 1) + rand) * rand_diffuse_shading
-        rand_shading = light_a[0, None].view(-1, 1, 1, 1) + alpha * rand + rand_diffuse
-        rand_light_im = (albedo[0, None] / 2 + 0.5) * rand_shading * 2 - 1
+        if rand.is_cuda and self.renderer.fused and normal.dtype == torch.float32:
+            # the same relighting through the fused shading kernel (csrc/geometry.hip shading_fwd computes
+            # a = l0/2 + .5, b = l1/2 + .5, direction = normalize(l2, l3, 1)): hand it the light vector
+            # whose a and b are light_a + alpha * rand and light_b + rand
+            from .fused_geometry import shading
+            if self._relight_consts is None:
+                self._relight_consts = torch.tensor([[2.0 * alpha, 2.0]], device=dev)
+            ab = torch.cat([light_a[:1].reshape(1, 1), light_b[:1].reshape(1, 1)], 1) * 2 - 1
+            light = torch.cat([ab + rand.view(-1, 1) * self._relight_consts, rand_light_dxy], 1)
+            _, rand_light_im = shading(normal[:1], light, albedo[:1])
+        else:
+            rand_light_d = torch.cat([rand_light_dxy, torch.ones(n_images, 1, device=dev)], 1)
+            rand_light_d = rand_light_d / ((rand_light_d ** 2).sum(1, keepdim=True)) ** 0.5
+            rand_diffuse_shading = (normal[0, None] * rand_light_d.view(-1, 1, 1, 3)).sum(3)\
+                .clamp(min=0).unsqueeze(1)
+            rand_diffuse = (light_b[0, None].view(-1, 1, 1, 1) + rand) * rand_diffuse_shading
+            rand_shading = light_a[0, None].view(-1, 1, 1, 1) + alpha * rand + rand_diffuse
+            rand_light_im = (albedo[0, None] / 2 + 0.5) * rand_shading * 2 - 1
 
         depth = depth[0, None]
         if canon_mask is not None:
@@ -535,8 +547,10 @@ class GAN2Shape(nn.Module):
 
 
 class ViewLightSampler():
-    """model.py:448-470.  Samples one at a time (n sequential MultivariateNormal draws) so that a
-    seeded run consumes the device generator in the reference's order."""
+    """model.py:448-470.  One standard-normal draw per sample, in sequence — n MultivariateNormal.sample()
+    calls consume the device generator exactly like this, so a seeded run sees the reference's draws —
+    then the affine map loc + L eps (and the view's yaw scale, folded into loc and L) for all n at
+    once: n + 1 launches instead of 5 n."""
 
     def __init__(self, view_mvn_path, light_mvn_path, view_scale, device="cuda",
                  view_mvn=None, light_mvn=None):
@@ -556,12 +570,17 @@ class ViewLightSampler():
         self.view_scale = view_scale
         self.view_dist = MultivariateNormal(vm.to(device), vc.to(device))
         self.light_dist = MultivariateNormal(lm.to(device), lc.to(device))
-
-    def _sample(self, sample_type):
-        sample = getattr(self, f'{sample_type}_dist').sample()[None, :]
-        if sample_type == 'view':
-            sample[0, 1] *= self.view_scale
-        return sample
+        self._affine = {}
+        for name, dist in (('view', self.view_dist), ('light', self.light_dist)):
+            scale = torch.ones_like(dist.loc)
+            if name == 'view':
+                scale[1] = view_scale            # sample[0, 1] *= view_scale (model.py:462-463)
+            tril = dist._unbroadcasted_scale_tril
+            self._affine[name] = ((dist.loc * scale)[None].contiguous(), (tril * scale[:, None]).t().contiguous())
 
     def sample(self, n=1, sample_type='view'):
-        return torch.cat([self._sample(sample_type) for _ in range(n)], dim=0)
+        loc, tril_t = self._affine[sample_type]
+        eps = torch.empty(n, loc.shape[1], dtype=loc.dtype, device=loc.device)
+        for row in eps:
+            row.normal_()                        # _standard_normal(event_shape) of one .sample() call
+        return torch.addmm(loc.expand(n, -1), eps, tril_t)

@@ -22,7 +22,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from .modconv import DOWN2, PLAIN, UP2, conv2d, conv2d_supported, conv_bias_act, demodulation, modconv
+from .modconv import DOWN2, PLAIN, UP2, conv2d, conv2d_supported, conv_bias_act, modconv, modconv_demod
 from .op import FusedLeakyReLU, add_bias_scale, fused_leaky_relu, fused_noise_bias_act, upfirdn2d
 
 
@@ -222,14 +222,15 @@ class ModulatedConv2d(nn.Module):
     def forward(self, input, style):
         s = style.s if isinstance(style, PreStyle) else self.modulation(style)  # [B, Cin] (model.py:253)
         w, wsq = self._weights()
-        demod = None
-        if self.demodulate:                             # model.py:256-258
-            demod = demodulation(s, wsq, self.eps)
+        if self.demodulate:                             # model.py:256-258, one node with the convolution
+            conv = lambda x, mode: modconv_demod(x, w, s, wsq, self.eps, mode)   # noqa: E731
+        else:
+            conv = lambda x, mode: modconv(x, w, s, None, mode)                  # noqa: E731
         if self.upsample:                               # model.py:264-275
-            return self.blur(modconv(input, w, s, demod, UP2))
+            return self.blur(conv(input, UP2))
         if self.downsample:                             # model.py:277-283
-            return modconv(self.blur(input), w, s, demod, DOWN2)
-        return modconv(input, w, s, demod, PLAIN)       # model.py:285-289
+            return conv(self.blur(input), DOWN2)
+        return conv(input, PLAIN)                       # model.py:285-289
 
 
 class NoiseInjection(nn.Module):

@@ -384,6 +384,10 @@ int g2s_demod_fwd(const float *wsq, const float *s, float *demod, int B, int Cin
                   float eps, g2s_stream_t stream);
 int g2s_demod_bwd(const float *wsq, const float *s, const float *demod, const float *gd, float *gs,
                   int B, int Cin, int Cout, g2s_stream_t stream);
+/* The same plus a gradient that reaches s from elsewhere (the convolution's own in_scale path):
+ * gs = gs_add + (the above); gs_add [B, Cin] may be NULL, may alias gs.  Saves autograd's accumulation launch. */
+int g2s_demod_bwd_add(const float *wsq, const float *s, const float *demod, const float *gd, const float *gs_add,
+                      float *gs, int B, int Cin, int Cout, g2s_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * LPIPS per-layer tail (csrc/lpips.hip): unit-normalise both feature maps over channels, weighted
