@@ -9,6 +9,7 @@
 //
 // Every backward is analytic; per-batch reductions (gradients of R and t) are reduced in the
 // workgroup and added with one float atomic per workgroup and component.
+#include <algorithm>
 #include "g2s_common.h"
 
 namespace g2s {
@@ -378,6 +379,53 @@ __global__ __launch_bounds__(256) void shading_bwd(const float *__restrict__ nor
     for (int k = 0; k < 4; k++) block_atomic_add(s[k], o + k, red);
 }
 
+// ------------------------------------------------------------------ depth head
+// model.py:337-345 get_clamped_depth + :323-324 rescale_depth on the depth net's raw map [n = B*H*W]:
+//   t = tanh(raw - mean),  d = (1 + t) / 2 * hi + (1 - t) / 2 * lo,
+//   out = d * (1 - b) + b * border_depth,  b = 1.02 in the two left / right columns, else 0
+// (mean: device scalar, the whole-batch mean the caller reduced).  The reference spends 14 launches on
+// this chain and as many again in autograd.
+struct DepthHead { float lo, hi, border_depth; int W, border; };
+
+__device__ __forceinline__ float border_weight(long i, const DepthHead &h) {
+    if (!h.border) return 0.0f;
+    const int col = (int)(i % h.W);
+    return (col < 2 || col >= h.W - 2) ? 1.02f : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void depth_head_fwd(const float *__restrict__ raw, const float *__restrict__ mean,
+                                                      float *__restrict__ out, long n, DepthHead h) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float t = tanhf(raw[i] - mean[0]);
+    const float d = (1.0f + t) / 2.0f * h.hi + (1.0f - t) / 2.0f * h.lo;
+    const float b = border_weight(i, h);
+    out[i] = d * (1.0f - b) + b * h.border_depth;
+}
+
+// gc = d out / d (raw - mean) * g; *gsum += sum gc (zeroed by the launcher).  The centring's own backward
+// (g_raw = gc - mean(gc)) is the second kernel.
+__global__ __launch_bounds__(256) void depth_head_bwd(const float *__restrict__ raw, const float *__restrict__ mean,
+                                                      const float *__restrict__ g, float *__restrict__ gc,
+                                                      float *__restrict__ gsum, long n, DepthHead h) {
+    __shared__ float red[4];
+    float acc = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float t = tanhf(raw[i] - mean[0]);
+        const float gd = g[i] * (1.0f - border_weight(i, h));
+        const float gt = gd * h.hi / 2.0f - gd * h.lo / 2.0f;
+        const float v = gt * (1.0f - t * t);
+        gc[i] = v;
+        acc += v;
+    }
+    block_atomic_add(acc, gsum, red);
+}
+
+__global__ __launch_bounds__(256) void sub_mean_kernel(float *__restrict__ x, const float *__restrict__ sum, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] -= sum[0] / (float)n;
+}
+
 static Intr make_intr(const float *K, int H, int W) {
     return Intr{K[0], K[1], K[2], K[3], K[4], K[5], 2.0f / (float)(W - 1), 2.0f / (float)(H - 1)};
 }
@@ -502,4 +550,24 @@ extern "C" int g2s_shading_bwd(const float *normal, const float *light, const fl
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
     shading_bwd<<<dim3(deterministic() ? 1 : cdiv(P, 256), B), 256, 0, st>>>(normal, light, albedo, gdiffuse, gtexture, gnormal, galbedo, glight, P, Bn, Ba);
     return check_launch("g2s_shading_bwd");
+}
+
+extern "C" int g2s_depth_head_fwd(const float *raw, const float *mean, float *out, int64_t n, int W, float lo,
+                                  float hi, int clamp_border, float border_depth, g2s_stream_t stream) {
+    G2S_REQUIRE(raw && mean && out && n > 0 && W >= 4 && n % W == 0, "bad argument (W >= 4 must divide n)");
+    depth_head_fwd<<<cdiv((long)n, 256), 256, 0, as_stream(stream)>>>(raw, mean, out, (long)n,
+                                                                     DepthHead{lo, hi, border_depth, W, clamp_border});
+    return check_launch("g2s_depth_head_fwd");
+}
+
+extern "C" int g2s_depth_head_bwd(const float *raw, const float *mean, const float *g, float *g_raw, float *gsum,
+                                  int64_t n, int W, float lo, float hi, int clamp_border, float border_depth,
+                                  g2s_stream_t stream) {
+    G2S_REQUIRE(raw && mean && g && g_raw && gsum && n > 0 && W >= 4 && n % W == 0, "bad argument");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(gsum, 0, sizeof(float), st) != hipSuccess) return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
+    const int blocks = deterministic() ? 1 : (int)std::min<long>(cdiv((long)n, 256), 1024);
+    depth_head_bwd<<<blocks, 256, 0, st>>>(raw, mean, g, g_raw, gsum, (long)n, DepthHead{lo, hi, border_depth, W, clamp_border});
+    sub_mean_kernel<<<cdiv((long)n, 256), 256, 0, st>>>(g_raw, gsum, (long)n);
+    return check_launch("g2s_depth_head_bwd");
 }

@@ -61,6 +61,61 @@ __global__ __launch_bounds__(WL1_THREADS) void wl1_bwd(const float *__restrict__
     }
 }
 
+// The same with the denominator in the pass: numden[0] += sum |x - y| * w, numden[1] += sum w (over b, c, p — the
+// reference's mask.expand_as(err).sum(); w == NULL: the element count), so that the loss is one division away.
+__global__ __launch_bounds__(WL1_THREADS) void wl1_fwd2(const float *__restrict__ x, const float *__restrict__ y,
+                                                        const float *__restrict__ w, float *__restrict__ numden,
+                                                        int C, int HW4, long total4) {
+    __shared__ float sm[4];
+    float acc = 0.0f, wsum = 0.0f;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *y4 = reinterpret_cast<const float4 *>(y);
+    const float4 *w4 = reinterpret_cast<const float4 *>(w);
+    for (long i = (long)blockIdx.x * WL1_THREADS + threadIdx.x; i < total4; i += (long)gridDim.x * WL1_THREADS) {
+        const float4 a = x4[i], b = y4[i];
+        float4 m = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        if (w) {
+            const long plane = i / HW4;              // b * C + c
+            m = w4[(plane / C) * HW4 + (i - plane * HW4)];
+        }
+        acc += (fabsf(a.x - b.x) * m.x + fabsf(a.y - b.y) * m.y) + (fabsf(a.z - b.z) * m.z + fabsf(a.w - b.w) * m.w);
+        wsum += (m.x + m.y) + (m.z + m.w);
+    }
+    const float s = wl1_block_sum(acc, sm);
+    __syncthreads();
+    const float d = wl1_block_sum(wsum, sm);
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(numden, s);
+        unsafeAtomicAdd(numden + 1, d);
+    }
+}
+
+// gx = gadd + sign(x - y) * w * g[0] / den[0]   (gadd may be NULL)
+__global__ __launch_bounds__(WL1_THREADS) void wl1_bwd2(const float *__restrict__ x, const float *__restrict__ y,
+                                                        const float *__restrict__ w, const float *__restrict__ g,
+                                                        const float *__restrict__ den, const float *__restrict__ gadd,
+                                                        float *__restrict__ gx, int C, int HW4, long total4) {
+    const float k = g[0] / den[0];
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *y4 = reinterpret_cast<const float4 *>(y);
+    const float4 *w4 = reinterpret_cast<const float4 *>(w), *a4 = reinterpret_cast<const float4 *>(gadd);
+    float4 *g4 = reinterpret_cast<float4 *>(gx);
+    for (long i = (long)blockIdx.x * WL1_THREADS + threadIdx.x; i < total4; i += (long)gridDim.x * WL1_THREADS) {
+        const float4 a = x4[i], b = y4[i];
+        float4 m = make_float4(k, k, k, k);
+        if (w) {
+            const long plane = i / HW4;
+            const float4 ww = w4[(plane / C) * HW4 + (i - plane * HW4)];
+            m = make_float4(ww.x * k, ww.y * k, ww.z * k, ww.w * k);
+        }
+        auto sgn = [](float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); };   // torch: sign(0) = 0
+        float4 r = make_float4(sgn(a.x - b.x) * m.x, sgn(a.y - b.y) * m.y, sgn(a.z - b.z) * m.z, sgn(a.w - b.w) * m.w);
+        if (gadd) {
+            const float4 e = a4[i];
+            r = make_float4(e.x + r.x, e.y + r.y, e.z + r.z, e.w + r.w);
+        }
+        g4[i] = r;
+    }
+}
+
 }  // namespace g2s
 
 using namespace g2s;
@@ -92,4 +147,26 @@ extern "C" int g2s_weighted_l1_bwd(const float *x, const float *y, const float *
     const int blocks = (int)std::min<long>(cdiv(total4, WL1_THREADS * 4), 4096);
     wl1_bwd<<<blocks, WL1_THREADS, 0, as_stream(stream)>>>(x, y, w, coef, gx, C, HW / 4, total4);
     return check_launch("g2s_weighted_l1_bwd");
+}
+
+extern "C" int g2s_weighted_l1_fwd2(const float *x, const float *y, const float *w, float *numden, int B, int C,
+                                    int HW, g2s_stream_t stream) {
+    int rc = wl1_check(x, y, B, C, HW);
+    if (rc) return rc;
+    G2S_REQUIRE(numden, "numden must not be NULL (two ZEROED device floats: numerator, denominator)");
+    const long total4 = (long)B * C * HW / 4;
+    const int blocks = deterministic() ? 1 : (int)std::min<long>(cdiv(total4, WL1_THREADS * 4), 2048);
+    wl1_fwd2<<<blocks, WL1_THREADS, 0, as_stream(stream)>>>(x, y, w, numden, C, HW / 4, total4);
+    return check_launch("g2s_weighted_l1_fwd2");
+}
+
+extern "C" int g2s_weighted_l1_bwd2(const float *x, const float *y, const float *w, const float *g, const float *den,
+                                    const float *gadd, float *gx, int B, int C, int HW, g2s_stream_t stream) {
+    int rc = wl1_check(x, y, B, C, HW);
+    if (rc) return rc;
+    G2S_REQUIRE(g && den && gx, "NULL pointer argument");
+    const long total4 = (long)B * C * HW / 4;
+    const int blocks = (int)std::min<long>(cdiv(total4, WL1_THREADS * 4), 4096);
+    wl1_bwd2<<<blocks, WL1_THREADS, 0, as_stream(stream)>>>(x, y, w, g, den, gadd, gx, C, HW / 4, total4);
+    return check_launch("g2s_weighted_l1_bwd2");
 }

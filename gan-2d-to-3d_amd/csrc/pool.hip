@@ -73,6 +73,49 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float *x, const
     }
 }
 
+// The entry of the offset encoder's residual block (GAN2Shape/networks.py:170-194): both branches start
+// from the same x — nn.ReLU() on the residual path, nn.AvgPool2d(2, 2) on the identity path.  One pass
+// writes both; the backward joins the two incoming gradients in one pass as well
+// (gx = ga * (x > 0) + gb / 4), where autograd runs threshold_backward, avg_pool2d_backward and an add.
+// Lane = one 2x2 window.  H, W even.
+__global__ __launch_bounds__(256) void res_split_fwd_kernel(const float *__restrict__ x, float *__restrict__ r,
+                                                            float *__restrict__ p, long windows, int OH, int OW) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= windows) return;
+    const int ox = (int)(i % OW);
+    const long row = i / OW;                     // (plane, output row)
+    const long plane = row / OH;
+    const int oy = (int)(row - plane * OH);
+    const long base = (plane * 2 * OH + 2 * oy) * (2L * OW) + 2 * ox;
+    const float2 t = *reinterpret_cast<const float2 *>(x + base), b = *reinterpret_cast<const float2 *>(x + base + 2 * OW);
+    auto relu = [](float v) { return v > 0.0f ? v : (v != v ? v : 0.0f); };   // NaN stays NaN, like torch
+    *reinterpret_cast<float2 *>(r + base) = make_float2(relu(t.x), relu(t.y));
+    *reinterpret_cast<float2 *>(r + base + 2 * OW) = make_float2(relu(b.x), relu(b.y));
+    p[i] = ((((0.0f + t.x) + t.y) + b.x) + b.y) / 4.0f;                        // ATen's accumulation order
+}
+
+__global__ __launch_bounds__(256) void res_split_bwd_kernel(const float *__restrict__ x, const float *__restrict__ ga,
+                                                            const float *__restrict__ gb, float *__restrict__ gx,
+                                                            long windows, int OH, int OW) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= windows) return;
+    const int ox = (int)(i % OW);
+    const long row = i / OW;
+    const long plane = row / OH;
+    const int oy = (int)(row - plane * OH);
+    const long base = (plane * 2 * OH + 2 * oy) * (2L * OW) + 2 * ox;
+    const float2 t = *reinterpret_cast<const float2 *>(x + base), b = *reinterpret_cast<const float2 *>(x + base + 2 * OW);
+    float2 at = make_float2(0.0f, 0.0f), ab = at;
+    if (ga) {
+        at = *reinterpret_cast<const float2 *>(ga + base);
+        ab = *reinterpret_cast<const float2 *>(ga + base + 2 * OW);
+    }
+    const float q = gb ? gb[i] / 4.0f : 0.0f;
+    auto gate = [](float g, float v) { return v > 0.0f ? g : 0.0f; };
+    *reinterpret_cast<float2 *>(gx + base) = make_float2(gate(at.x, t.x) + q, gate(at.y, t.y) + q);
+    *reinterpret_cast<float2 *>(gx + base + 2 * OW) = make_float2(gate(ab.x, b.x) + q, gate(ab.y, b.y) + q);
+}
+
 }  // namespace g2s
 
 using namespace g2s;
@@ -102,4 +145,30 @@ extern "C" int g2s_maxpool2x2_bwd(const float *x, const float *gy, float *gx, in
     maxpool2_bwd_kernel<<<(unsigned)std::min<long>((quads + 255) / 256, 256 * 8), 256, 0, as_stream(stream)>>>(
         x, gy, gx, quads, H / 2, W / 8);
     return check_launch("g2s_maxpool2x2_bwd");
+}
+
+static int res_split_check(int64_t planes, int H, int W) {
+    G2S_REQUIRE(planes > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "planes, H, W positive; H, W even");
+    G2S_REQUIRE(planes * H * W < (1LL << 40), "tensor too large");
+    return G2S_OK;
+}
+
+extern "C" int g2s_res_split_fwd(const float *x, float *relu_out, float *pool_out, int64_t planes, int H, int W,
+                                 g2s_stream_t stream) {
+    G2S_REQUIRE(x && relu_out && pool_out, "NULL pointer argument");
+    int rc = res_split_check(planes, H, W);
+    if (rc) return rc;
+    const long windows = (long)planes * (H / 2) * (W / 2);
+    res_split_fwd_kernel<<<cdiv(windows, 256), 256, 0, as_stream(stream)>>>(x, relu_out, pool_out, windows, H / 2, W / 2);
+    return check_launch("g2s_res_split_fwd");
+}
+
+extern "C" int g2s_res_split_bwd(const float *x, const float *g_relu, const float *g_pool, float *gx, int64_t planes,
+                                 int H, int W, g2s_stream_t stream) {
+    G2S_REQUIRE(x && gx && (g_relu || g_pool), "NULL pointer argument (one of g_relu / g_pool may be NULL)");
+    int rc = res_split_check(planes, H, W);
+    if (rc) return rc;
+    const long windows = (long)planes * (H / 2) * (W / 2);
+    res_split_bwd_kernel<<<cdiv(windows, 256), 256, 0, as_stream(stream)>>>(x, g_relu, g_pool, gx, windows, H / 2, W / 2);
+    return check_launch("g2s_res_split_bwd");
 }

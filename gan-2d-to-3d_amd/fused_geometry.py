@@ -207,6 +207,35 @@ def normal_from_depth(depth, rays):
     return NormalFunction.apply(depth, rays)
 
 
+class DepthHeadFunction(Function):
+    """model.py:337-345 get_clamped_depth (+ rescale_depth): centre over the whole batch, tanh, rescale to
+    [lo, hi], blend the border columns — two launches forward (the mean, then everything else), three
+    backward, where the op-by-op chain takes 14 each way."""
+
+    @staticmethod
+    def forward(ctx, raw, W, lo, hi, clamp_border, border_depth):
+        raw = _f32c(raw)
+        mean = raw.view(1, -1).mean(1)
+        out = torch.empty_like(raw)
+        ctx.args = (raw.numel(), int(W), float(lo), float(hi), int(bool(clamp_border)), float(border_depth))
+        _lib.check(_lib.load().g2s_depth_head_fwd(_lib.ptr(raw), _lib.ptr(mean), _lib.ptr(out), *ctx.args, _lib.stream()))
+        ctx.save_for_backward(raw, mean)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        raw, mean = ctx.saved_tensors
+        g_raw = torch.empty_like(raw)
+        gsum = torch.empty(1, dtype=torch.float32, device=raw.device)
+        _lib.check(_lib.load().g2s_depth_head_bwd(_lib.ptr(raw), _lib.ptr(mean), _lib.ptr(_f32c(g)), _lib.ptr(g_raw),
+                                                  _lib.ptr(gsum), *ctx.args, _lib.stream()))
+        return g_raw, None, None, None, None, None
+
+
+def depth_head(raw, W, lo, hi, clamp_border, border_depth):
+    return DepthHeadFunction.apply(raw, W, lo, hi, clamp_border, border_depth)
+
+
 def shading(normal, light, albedo):
     return ShadingFunction.apply(normal, light, albedo)
 

@@ -19,6 +19,10 @@ SIGNATURES = {
     "g2s_abi_version": (_i, []),
     "g2s_last_error": (C.c_char_p, []),
     "g2s_clamp": (_i, [_p, _p, _p, _i64, _f, _f, _i, _p]),
+    "g2s_res_split_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _p]),
+    "g2s_res_split_bwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p]),
+    "g2s_depth_head_fwd": (_i, [_p, _p, _p, _i64, _i, _f, _f, _i, _f, _p]),
+    "g2s_depth_head_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _f, _i, _f, _p]),
     "g2s_grid_sample_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
     "g2s_grid_sample_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "g2s_grid_sample_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),
@@ -62,6 +66,8 @@ SIGNATURES = {
     "g2s_lpips_layer_bwd_ex": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
     "g2s_weighted_l1_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_weighted_l1_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "g2s_weighted_l1_fwd2": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "g2s_weighted_l1_bwd2": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_view_transform_fwd": (_i, [_p, _f, _f, _f, _p, _p, _i, _p]),
     "g2s_view_transform_bwd": (_i, [_p, _f, _f, _f, _p, _p, _p, _i, _p]),
     "g2s_warp_verts_fwd": (_i, [_p, _p, _p, _p, _f, _p, _i, _i, _p]),

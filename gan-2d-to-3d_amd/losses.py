@@ -24,26 +24,21 @@ class _WeightedL1(torch.autograd.Function):
         from . import lib as _lib
         x, y = x.contiguous(), y.contiguous()
         B, C, H, W = x.shape
-        L = _lib.load()
-        num = torch.zeros((), dtype=torch.float32, device=x.device)
+        numden = torch.zeros(2, dtype=torch.float32, device=x.device)   # numerator, mask.expand_as(err).sum()
         wc = None if w is None else w.contiguous()
-        _lib.check(L.g2s_weighted_l1_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(wc), _lib.ptr(num), B, C, H * W,
-                                         _lib.stream()))
-        den = (wc.sum() * C) if wc is not None else float(x.numel())
-        ctx.save_for_backward(x, y, wc, den if torch.is_tensor(den) else None)
-        ctx.den = None if torch.is_tensor(den) else den
-        return num / den
+        _lib.check(_lib.load().g2s_weighted_l1_fwd2(_lib.ptr(x), _lib.ptr(y), _lib.ptr(wc), _lib.ptr(numden), B, C,
+                                                    H * W, _lib.stream()))
+        ctx.save_for_backward(x, y, wc, numden)
+        return numden[0] / numden[1]
 
     @staticmethod
     def backward(ctx, g):
         from . import lib as _lib
-        x, y, wc, den = ctx.saved_tensors
-        coef = (g / (den if den is not None else ctx.den)).reshape(1).float().contiguous()
+        x, y, wc, numden = ctx.saved_tensors
         gx = torch.empty_like(x)
         B, C, H, W = x.shape
-        L = _lib.load()
-        _lib.check(L.g2s_weighted_l1_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(wc), _lib.ptr(coef), _lib.ptr(gx), B, C,
-                                         H * W, _lib.stream()))
+        _lib.check(_lib.load().g2s_weighted_l1_bwd2(_lib.ptr(x), _lib.ptr(y), _lib.ptr(wc), _lib.ptr(g.contiguous()),
+                                                    _lib.ptr(numden[1:]), None, _lib.ptr(gx), B, C, H * W, _lib.stream()))
         return gx, None, None
 
 
@@ -80,31 +75,23 @@ class _DFeatureL1(torch.autograd.Function):
         first = D.convs[0]
         y0 = first(x)
         blocks, out = [], y0
-        nums, dens = [], []
+        numden = torch.zeros(count, 2, dtype=torch.float32, device=x.device)   # per level: numerator, sum of weights
         for i in range(1, count + 1):
             blk = D.convs[i]
+            in_hw = out.shape[2:]
             y1 = blk.conv1(out)
             y2 = blk.conv2(y1)
             sk = blk.skip(out)
-            nxt = add_bias_scale(y2, sk, None, 2 ** -0.5)
-            blocks.append((blk, out.shape[2:], y1, y2))
-            out = nxt
+            out = add_bias_scale(y2, sk, None, 2 ** -0.5)
             B2, C, H, W = out.shape
             w = weights[i - 1]
             wc = None if w is None else w.contiguous()
-            num = torch.zeros((), dtype=torch.float32, device=out.device)
-            _lib.check(L.g2s_weighted_l1_fwd(_lib.ptr(out[:N]), _lib.ptr(out[N:]), _lib.ptr(wc), _lib.ptr(num), N, C,
-                                             H * W, _lib.stream()))
-            den = (wc.sum() * C) if wc is not None else torch.tensor(float(N * C * H * W), device=out.device)
-            nums.append(num)
-            dens.append(den)
-            blocks[-1] = blocks[-1] + (out, wc)
+            _lib.check(L.g2s_weighted_l1_fwd2(_lib.ptr(out[:N]), _lib.ptr(out[N:]), _lib.ptr(wc), _lib.ptr(numden[i - 1]),
+                                              N, C, H * W, _lib.stream()))
+            blocks.append((blk, in_hw, y1, y2, out, wc))
         ctx.D, ctx.N, ctx.first, ctx.y0 = D, N, first, y0
-        ctx.blocks, ctx.dens = blocks, dens
-        total = nums[0] / dens[0]
-        for n_, d_ in zip(nums[1:], dens[1:]):
-            total = total + n_ / d_
-        return total
+        ctx.blocks, ctx.numden = blocks, numden
+        return (numden[:, 0] / numden[:, 1]).sum()
 
     @staticmethod
     def backward(ctx, g_total):
@@ -116,14 +103,16 @@ class _DFeatureL1(torch.autograd.Function):
         N = ctx.N
         slope, gain = 0.2, 2 ** 0.5
         g = None
-        for (blk, in_hw, y1, y2, feat, wc), den in zip(reversed(ctx.blocks), reversed(ctx.dens)):
-            # masked L1 of this level, gradient w.r.t. the fake half
-            coef = (g_total / den).reshape(1).float().contiguous()
+        g_total = g_total.contiguous()
+        for level in range(len(ctx.blocks) - 1, -1, -1):
+            blk, in_hw, y1, y2, feat, wc = ctx.blocks[level]
+            # masked L1 of this level, gradient w.r.t. the fake half, added to what arrives from the next level
             B2, C, H, W = feat.shape
             gl = torch.empty((N, C, H, W), dtype=torch.float32, device=feat.device)
-            _lib.check(L.g2s_weighted_l1_bwd(_lib.ptr(feat[:N]), _lib.ptr(feat[N:]), _lib.ptr(wc), _lib.ptr(coef),
-                                             _lib.ptr(gl), N, C, H * W, _lib.stream()))
-            g = gl if g is None else g + gl
+            _lib.check(L.g2s_weighted_l1_bwd2(_lib.ptr(feat[:N]), _lib.ptr(feat[N:]), _lib.ptr(wc), _lib.ptr(g_total),
+                                              _lib.ptr(ctx.numden[level, 1:]), _lib.ptr(g), _lib.ptr(gl), N, C, H * W,
+                                              _lib.stream()))
+            g = gl
             # out = (conv2(conv1(x)) + skip(x)) / sqrt(2): both branches keep the common factor, the join applies it
             conv2, conv1, skip = blk.conv2, blk.conv1, blk.skip
             w2 = conv2[-2]._w.get(conv2[-2].weight, conv2[-2].scale)

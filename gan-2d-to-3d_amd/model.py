@@ -188,6 +188,10 @@ class GAN2Shape(nn.Module):
         columns blend towards border_depth with weight 1.02."""
         # batch_mean: None = this process holds the whole batch; the joint trainer under data
         # parallelism sets sharding.global_mean so that the centre stays the WHOLE-batch mean
+        if self.batch_mean is None and depth_raw.is_cuda and self.renderer.fused and depth_raw.dtype == torch.float32 \
+                and depth_raw.shape[-1] == w and w >= 4:
+            from .fused_geometry import depth_head     # the whole chain below as one kernel each way
+            return depth_head(depth_raw, w, self.min_depth, self.max_depth, clamp_border, self.border_depth)
         mean = depth_raw.view(1, -1).mean(1) if self.batch_mean is None else self.batch_mean(depth_raw)
         depth_centered = depth_raw - mean.view(1, 1, 1)
         depth = self.rescale_depth(torch.tanh(depth_centered))
@@ -217,7 +221,8 @@ class GAN2Shape(nn.Module):
         if lighting.is_cuda and self.renderer.fused:
             from .fused_geometry import shading
             diffuse_shading, texture = shading(normal, lighting, albedo)
-            return lighting[:, :1] / 2 + 0.5, lighting[:, 1:2] / 2 + 0.5, diffuse_shading, texture
+            ab = lighting[:, :2] / 2 + 0.5          # ambience and diffuse terms, one pass for both
+            return ab[:, :1], ab[:, 1:2], diffuse_shading, texture
         lighting_a, lighting_b, lighting_d = self.get_lighting_directions(lighting)
         diffuse_shading, texture = self.get_shading(normal, lighting_a, lighting_b, lighting_d, albedo)
         return lighting_a, lighting_b, diffuse_shading, texture

@@ -267,6 +267,35 @@ class AlbedoNet(EncoderDecoder):
         super().__init__(cin=3, cout=3, size=image_size, activation=nn.Tanh)
 
 
+class _ResSplit(torch.autograd.Function):
+    """x -> (relu(x), avg_pool2d(x, 2, 2)): the two branch entries of ResBlock in one launch; backward joins
+    the two gradients in one launch (g2s_res_split_*)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import lib as _lib
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        r = torch.empty_like(x)
+        p = torch.empty((B, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.load().g2s_res_split_fwd(_lib.ptr(x), _lib.ptr(r), _lib.ptr(p), B * C, H, W, _lib.stream()))
+        ctx.save_for_backward(x)
+        return r, p
+
+    @staticmethod
+    def backward(ctx, gr, gp):
+        from . import lib as _lib
+        (x,) = ctx.saved_tensors
+        if gr is None and gp is None:
+            return None
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        _lib.check(_lib.load().g2s_res_split_bwd(_lib.ptr(x), _lib.ptr(None if gr is None else gr.contiguous()),
+                                                 _lib.ptr(None if gp is None else gp.contiguous()), _lib.ptr(gx), B * C, H, W,
+                                                 _lib.stream()))
+        return gx
+
+
 class ResBlock(nn.Module):
     """Residual block of the offset encoder (networks.py:170-194)."""
 
@@ -281,6 +310,10 @@ class ResBlock(nn.Module):
 
     def forward(self, x):
         if x.is_cuda:
+            if x.dtype == torch.float32 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 \
+                    and isinstance(self.res_path[0], nn.ReLU) and isinstance(self.identity_path[0], nn.AvgPool2d):
+                r, p = _ResSplit.apply(x)          # the leading ReLU and the 2x2 average in one pass over x
+                return run_fused(self.identity_path[1:], p) + run_fused(self.res_path[1:], r)
             return run_fused(self.identity_path, x) + run_fused(self.res_path, x)
         return self.identity_path(x) + self.res_path(x)
 

@@ -151,6 +151,25 @@ int g2s_maxpool2x2_bwd(const float *x, const float *gy, float *gx, int64_t plane
 int g2s_add_bias_scale(const float *a, const float *b, const float *bias, float *y, int64_t n, int64_t hw, int C,
                        float scale, g2s_stream_t stream);
 
+/* Entry of the offset encoder's residual block (GAN2Shape/networks.py:170-194): relu_out = relu(x) for the
+ * residual path and pool_out = avg_pool2d(x, 2, 2) for the identity path in one pass over x [planes, H, W]
+ * (H, W even); backward gx = g_relu * (x > 0) + g_pool / 4 in one pass (either gradient may be NULL). */
+int g2s_res_split_fwd(const float *x, float *relu_out, float *pool_out, int64_t planes, int H, int W,
+                      g2s_stream_t stream);
+int g2s_res_split_bwd(const float *x, const float *g_relu, const float *g_pool, float *gx, int64_t planes, int H,
+                      int W, g2s_stream_t stream);
+
+/* The depth head (GAN2Shape/model.py:337-345 get_clamped_depth with :323-324 rescale_depth) on the depth net's
+ * raw map, raw [n = B*H*W] f32:  t = tanh(raw - mean[0]);  d = (1 + t) / 2 * hi + (1 - t) / 2 * lo;
+ * clamp_border: out = d * (1 - b) + b * border_depth with b = 1.02 in the two left / right columns of every
+ * row of W, else 0.  mean: device float (the whole-batch mean of raw, reduced by the caller — under data
+ * parallelism the all-reduced one).  _bwd: g_raw = gc - mean(gc), gc = g * d out / d (raw - mean) — the
+ * centring's own backward included (mean taken over these n elements); gsum: one device float of scratch. */
+int g2s_depth_head_fwd(const float *raw, const float *mean, float *out, int64_t n, int W, float lo, float hi,
+                       int clamp_border, float border_depth, g2s_stream_t stream);
+int g2s_depth_head_bwd(const float *raw, const float *mean, const float *g, float *g_raw, float *gsum, int64_t n,
+                       int W, float lo, float hi, int clamp_border, float border_depth, g2s_stream_t stream);
+
 /* The reconstruction warp: torch.nn.functional.grid_sample(x, grid, mode='bilinear', padding_mode='zeros',
  * align_corners=True) as GAN2Shape/model.py:147,267 calls it, optionally followed by .clamp(lo, hi)
  * (model.py:150,270) in the same pass (clamp = 1).  ATen's arithmetic (corner order nw, ne, sw, se).
@@ -420,6 +439,15 @@ int g2s_weighted_l1_fwd(const float *x, const float *y, const float *w, float *n
                         g2s_stream_t stream);
 int g2s_weighted_l1_bwd(const float *x, const float *y, const float *w, const float *coef, float *gx, int B,
                         int C, int HW, g2s_stream_t stream);
+/* The loss one division away, in the same two passes:
+ * _fwd2: numden[0] += sum |x - y| * w,  numden[1] += sum over (b, c, p) of w — the reference's
+ *        mask.expand_as(loss).sum(); w == NULL: the element count.  numden: two ZEROED device floats.
+ * _bwd2: gx = gadd + sign(x - y) * w * g[0] / den[0]   (g: incoming gradient, den: numden + 1, both device
+ *        floats; gadd [B, C, HW] another gradient reaching x, or NULL). */
+int g2s_weighted_l1_fwd2(const float *x, const float *y, const float *w, float *numden, int B, int C, int HW,
+                         g2s_stream_t stream);
+int g2s_weighted_l1_bwd2(const float *x, const float *y, const float *w, const float *g, const float *den,
+                         const float *gadd, float *gx, int B, int C, int HW, g2s_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused renderer geometry / loss glue (csrc/geometry.hip).  All f32, device pointers; K is a HOST

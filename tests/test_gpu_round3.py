@@ -401,3 +401,108 @@ def test_graph_replayed_training_run_is_bitwise_reproducible_in_deterministic_mo
     assert la == lb, (la, lb)
     differing = [k for k in pa if not torch.equal(pa[k], pb[k])]
     assert not differing, (len(differing), len(pa), differing[:5])
+
+
+# ----------------------------------------------------------------------- launch-count kernels of round 3
+@pytest.mark.parametrize("masked", [True, False])
+def test_weighted_l1_with_denominator_and_joined_gradient(L, masked):
+    """g2s_weighted_l1_fwd2 / _bwd2 against the reference's expression (losses.py:40-51:
+    (|a - b| * mask.expand_as).sum() / mask.expand_as.sum()), plus the gradient that joins in."""
+    from gan2shape_amd import lib
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 4, 6, 16, 24
+    x, y = torch.randn(B, C, H, W, generator=g).cuda(), torch.randn(B, C, H, W, generator=g).cuda()
+    w = (torch.rand(B, 1, H, W, generator=g) > 0.3).float().cuda() if masked else None
+    gadd = torch.randn(B, C, H, W, generator=g).cuda()
+    numden = torch.zeros(2, device="cuda")
+    lib.check(L.g2s_weighted_l1_fwd2(lib.ptr(x), lib.ptr(y), lib.ptr(w), lib.ptr(numden), B, C, H * W, lib.stream()))
+    xr = x.double().requires_grad_(True)
+    wd = torch.ones(B, 1, H, W, device="cuda", dtype=torch.float64) if w is None else w.double()
+    err = (xr - y.double()).abs()
+    ref = (err * wd.expand_as(err)).sum() / wd.expand_as(err).sum()
+    assert abs(float(numden[0] / numden[1]) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert abs(float(numden[1]) - float(wd.expand_as(err).sum())) <= 1e-6 * float(numden[1])
+    gout = torch.tensor([0.7], device="cuda")
+    (gref,) = torch.autograd.grad(ref, xr, gout.double()[0])
+    gx = torch.empty_like(x)
+    lib.check(L.g2s_weighted_l1_bwd2(lib.ptr(x), lib.ptr(y), lib.ptr(w), lib.ptr(gout), lib.ptr(numden[1:]), lib.ptr(gadd),
+                                     lib.ptr(gx), B, C, H * W, lib.stream()))
+    assert float((gx.double() - (gref + gadd.double())).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("clamp_border", [True, False])
+def test_depth_head_matches_the_op_by_op_chain(L, clamp_border):
+    """g2s_depth_head_* against get_clamped_depth's torch chain (GAN2Shape/model.py:337-345): values and the
+    gradient w.r.t. the raw map, the whole-batch centring included."""
+    from gan2shape_amd.fused_geometry import depth_head
+    g = torch.Generator().manual_seed(4)
+    B, H, W = 3, 32, 32
+    raw = (torch.randn(B, H, W, generator=g) * 0.8 + 0.3).cuda()
+    gout = torch.randn(B, H, W, generator=g).cuda()
+    lo, hi, bd = 0.9, 1.1, 0.7 * 1.1 + 0.3 * 0.9
+
+    def chain(r):
+        mean = r.view(1, -1).mean(1)
+        t = torch.tanh(r - mean.view(1, 1, 1))
+        d = (1 + t) / 2 * hi + (1 - t) / 2 * lo
+        if clamp_border:
+            border = torch.nn.functional.pad(torch.zeros(1, H, W - 4, device=r.device), (2, 2), mode="constant", value=1.02)
+            d = d * (1 - border) + border * bd
+        return d
+    outs = []
+    for fn in (lambda r: depth_head(r, W, lo, hi, clamp_border, bd), chain):
+        r = raw.clone().requires_grad_(True)
+        d = fn(r)
+        d.backward(gout)
+        outs.append((d.detach(), r.grad))
+    (d1, g1), (d0, g0) = outs
+    assert float((d1 - d0).abs().max()) <= 2e-7
+    assert float((g1 - g0).abs().max()) <= 1e-6 * float(g0.abs().max()) + 1e-9
+
+
+def test_res_split_matches_relu_and_avg_pool(L):
+    import torch.nn.functional as F
+    from gan2shape_amd.networks import _ResSplit
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 32, 16, 24, generator=g).cuda()
+    gr, gp = torch.randn(4, 32, 16, 24, generator=g).cuda(), torch.randn(4, 32, 8, 12, generator=g).cuda()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    r, p = _ResSplit.apply(xa)
+    torch.autograd.backward([r, p], [gr, gp])
+    r0, p0 = F.relu(xb), F.avg_pool2d(xb, 2, 2)
+    torch.autograd.backward([r0, p0], [gr, gp])
+    assert torch.equal(r, r0) and torch.equal(p, p0)
+    assert torch.equal(xa.grad, xb.grad)
+    # one branch only
+    xc = x.clone().requires_grad_(True)
+    _ResSplit.apply(xc)[1].backward(gp)
+    xd = x.clone().requires_grad_(True)
+    F.avg_pool2d(xd, 2, 2).backward(gp)
+    assert torch.equal(xc.grad, xd.grad)
+
+
+def test_modconv_demod_one_node_equals_two_nodes(L):
+    """ModConvDemodFunction (style gradient joined inside g2s_demod_bwd_add) against demodulation + modconv
+    as two autograd nodes: identical outputs, input gradients and style gradients."""
+    from gan2shape_amd import modconv as mc
+    g = torch.Generator().manual_seed(6)
+    B, cin, cout, H = 4, 64, 32, 16
+    x = torch.randn(B, cin, H, H, generator=g).cuda()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
+    s = (1 + 0.3 * torch.randn(B, cin, generator=g)).cuda()
+    wsq = w.pow(2).sum((2, 3))
+    gy = torch.randn(B, cout, H, H, generator=g).cuda()
+    from gan2shape_amd import lib
+    res = []
+    lib.set_deterministic(True)      # fixed partitions: the two forms can be compared bit for bit
+    try:
+        for one in (True, False):
+            xx, ss = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+            y = mc.modconv_demod(xx, w, ss, wsq, 1e-8, mc.PLAIN) if one else \
+                mc.modconv(xx, w, ss, mc.demodulation(ss, wsq, 1e-8), mc.PLAIN)
+            y.backward(gy)
+            res.append((y.detach(), xx.grad, ss.grad))
+    finally:
+        lib.set_deterministic(False)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
