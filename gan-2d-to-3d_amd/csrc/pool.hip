@@ -116,6 +116,56 @@ __global__ __launch_bounds__(256) void res_split_bwd_kernel(const float *__restr
     *reinterpret_cast<float2 *>(gx + base + 2 * OW) = make_float2(gate(ab.x, b.x) + q, gate(ab.y, b.y) + q);
 }
 
+// The mask pyramid of the discriminator-feature loss (GAN2Shape/losses.py:24-30: the mask box-averaged down
+// to every feature resolution): LEVELS successive avg_pool2d(., 2, 2) of a [planes, H, W] map in one launch.
+// One lane owns a (2^LEVELS)^2 input block and reduces it level by level in registers, in ATen's order
+// (((a + b) + c) + d) / 4 per window.
+template <int LEVELS>
+__global__ __launch_bounds__(64) void avg_pyramid_kernel(const float *__restrict__ x, float *__restrict__ o1,
+                                                         float *__restrict__ o2, float *__restrict__ o3,
+                                                         float *__restrict__ o4, long blocks, int H, int W) {
+    constexpr int S = 1 << LEVELS;
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
+    if (i >= blocks) return;
+    const int bw = W / S, bh = H / S;
+    const int bx = (int)(i % bw);
+    const long r = i / bw;
+    const long plane = r / bh;
+    const int by = (int)(r - plane * bh);
+    float cur[S / 2][S / 2];
+    const float *src = x + (plane * H + (long)by * S) * W + (long)bx * S;
+#pragma unroll
+    for (int yy = 0; yy < S / 2; yy++)
+#pragma unroll
+        for (int xx = 0; xx < S / 2; xx++) {
+            const float2 t = *reinterpret_cast<const float2 *>(src + (2 * yy) * W + 2 * xx);
+            const float2 b = *reinterpret_cast<const float2 *>(src + (2 * yy + 1) * W + 2 * xx);
+            cur[yy][xx] = ((((0.0f + t.x) + t.y) + b.x) + b.y) / 4.0f;
+        }
+    float *outs[4] = {o1, o2, o3, o4};
+    int side = S / 2;
+#pragma unroll
+    for (int l = 0; l < LEVELS; l++) {
+        const int lw = W >> (l + 1), lh = H >> (l + 1);
+        float *dst = outs[l] + (plane * lh + (long)by * side) * lw + (long)bx * side;
+#pragma unroll
+        for (int yy = 0; yy < S / 2; yy++)
+#pragma unroll
+            for (int xx = 0; xx < S / 2; xx++)
+                if (yy < side && xx < side) dst[yy * lw + xx] = cur[yy][xx];
+        if (l + 1 < LEVELS) {
+#pragma unroll
+            for (int yy = 0; yy < S / 4; yy++)
+#pragma unroll
+                for (int xx = 0; xx < S / 4; xx++)
+                    if (yy < side / 2 && xx < side / 2)
+                        cur[yy][xx] = ((((0.0f + cur[2 * yy][2 * xx]) + cur[2 * yy][2 * xx + 1]) + cur[2 * yy + 1][2 * xx]) +
+                                       cur[2 * yy + 1][2 * xx + 1]) / 4.0f;
+            side /= 2;
+        }
+    }
+}
+
 }  // namespace g2s
 
 using namespace g2s;
@@ -171,4 +221,24 @@ extern "C" int g2s_res_split_bwd(const float *x, const float *g_relu, const floa
     const long windows = (long)planes * (H / 2) * (W / 2);
     res_split_bwd_kernel<<<cdiv(windows, 256), 256, 0, as_stream(stream)>>>(x, g_relu, g_pool, gx, windows, H / 2, W / 2);
     return check_launch("g2s_res_split_bwd");
+}
+
+extern "C" int g2s_avg_pyramid(const float *x, float *const *levels, int n_levels, int64_t planes, int H, int W,
+                               g2s_stream_t stream) {
+    G2S_REQUIRE(x && levels && planes > 0 && n_levels >= 1 && n_levels <= 4, "bad argument (1 <= n_levels <= 4)");
+    const int S = 1 << n_levels;
+    G2S_REQUIRE(H > 0 && W > 0 && H % S == 0 && W % S == 0, "H and W must be multiples of 2^n_levels");
+    for (int l = 0; l < n_levels; l++) G2S_REQUIRE(levels[l], "NULL level pointer");
+    float *o[4] = {levels[0], n_levels > 1 ? levels[1] : nullptr, n_levels > 2 ? levels[2] : nullptr,
+                   n_levels > 3 ? levels[3] : nullptr};
+    const long blocks = (long)planes * (H / S) * (W / S);
+    hipStream_t st = as_stream(stream);
+    const int grid = (int)cdiv(blocks, 64);
+    switch (n_levels) {
+        case 1: avg_pyramid_kernel<1><<<grid, 64, 0, st>>>(x, o[0], o[1], o[2], o[3], blocks, H, W); break;
+        case 2: avg_pyramid_kernel<2><<<grid, 64, 0, st>>>(x, o[0], o[1], o[2], o[3], blocks, H, W); break;
+        case 3: avg_pyramid_kernel<3><<<grid, 64, 0, st>>>(x, o[0], o[1], o[2], o[3], blocks, H, W); break;
+        default: avg_pyramid_kernel<4><<<grid, 64, 0, st>>>(x, o[0], o[1], o[2], o[3], blocks, H, W); break;
+    }
+    return check_launch("g2s_avg_pyramid");
 }

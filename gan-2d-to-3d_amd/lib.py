@@ -19,6 +19,7 @@ SIGNATURES = {
     "g2s_abi_version": (_i, []),
     "g2s_last_error": (C.c_char_p, []),
     "g2s_clamp": (_i, [_p, _p, _p, _i64, _f, _f, _i, _p]),
+    "g2s_avg_pyramid": (_i, [_p, _p, _i, _i64, _i, _i, _p]),
     "g2s_res_split_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _p]),
     "g2s_res_split_bwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p]),
     "g2s_depth_head_fwd": (_i, [_p, _p, _p, _i64, _i, _f, _f, _i, _f, _p]),

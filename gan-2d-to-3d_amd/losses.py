@@ -135,6 +135,25 @@ class _DFeatureL1(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+def _mask_pyramid(mask, levels):
+    """[avg_pool2d(mask, 2, 2), avg_pool2d of that, ...]: one launch (g2s_avg_pyramid) for up to 4 levels."""
+    if mask is None:
+        return [None] * levels
+    if not (1 <= levels <= 4 and mask.is_cuda and mask.dtype == torch.float32):
+        out, w = [], mask
+        for _ in range(levels):
+            w = F.avg_pool2d(w, 2, 2)
+            out.append(w)
+        return out
+    from . import lib as _lib
+    m = mask.contiguous()
+    B, C, H, W = m.shape
+    out = [torch.empty((B, C, H >> (l + 1), W >> (l + 1)), dtype=torch.float32, device=m.device) for l in range(levels)]
+    ptrs = (_lib.C.c_void_p * levels)(*[t.data_ptr() for t in out])
+    _lib.check(_lib.load().g2s_avg_pyramid(_lib.ptr(m), ptrs, levels, B * C, H, W, _lib.stream()))
+    return out
+
+
 def _d_one_node_ok(D, fake, real, count):
     from .stylegan2 import ConvLayer, ResBlock
     from .op import FusedLeakyReLU
@@ -175,10 +194,7 @@ class DiscriminatorLoss():
                 mask is None or (mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[0] == fake_img.shape[0]
                                  and mask.shape[2:] == fake_img.shape[2:] and not mask.requires_grad
                                  and mask.shape[2] % (2 ** self.ftr_num) == 0 and mask.shape[3] % (2 ** self.ftr_num) == 0)):
-            weights, w = [], mask
-            for _ in range(self.ftr_num):      # feature level l lives at 1 / 2^l of the image: 2x2 box averages
-                w = None if w is None else F.avg_pool2d(w, 2, 2)
-                weights.append(w)
+            weights = _mask_pyramid(mask, self.ftr_num)   # level l lives at 1 / 2^l of the image: 2x2 box averages
             return _DFeatureL1.apply(fake_img, real_img.detach(), D, self.ftr_num, weights)
         with torch.no_grad():
             real = self._features(D, real_img.detach())

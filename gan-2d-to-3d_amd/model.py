@@ -414,10 +414,13 @@ class GAN2Shape(nn.Module):
         else:
             mask = torch.ones(n_images, 3, h, w, device=dev)
 
-        rand_views = self.view_light_sampler.sample(n_images, 'view')
         if _draws is not None:
-            rand_views = _draws[2].to(dev)
-        rand_views_trans = self.get_view_transformation(rand_views)
+            rand_views_trans = self.get_view_transformation(_draws[2].to(dev))
+        else:       # get_view_transformation of the draws, its three factors folded into the sampler's affine map
+            rot = math.pi / 180 * self.xyz_rotation_range
+            rand_views_trans = self.view_light_sampler.sample(
+                n_images, 'view', scale=(rot, rot, rot, self.xy_translation_range, self.xy_translation_range,
+                                         self.z_translation_range))
         pseudo_im, mask = self.renderer.render_given_view(rand_light_im, depth.expand(n_images, h, w),
                                                           view=rand_views_trans, mask=mask,
                                                           grid_sample=True)
@@ -583,8 +586,16 @@ class ViewLightSampler():
             tril = dist._unbroadcasted_scale_tril
             self._affine[name] = ((dist.loc * scale)[None].contiguous(), (tril * scale[:, None]).t().contiguous())
 
-    def sample(self, n=1, sample_type='view'):
+    def sample(self, n=1, sample_type='view', scale=None):
+        """`scale` (a tuple, one factor per component): the samples times these factors — folded into the
+        affine map, so get_view_transformation (model.py:330-335) of the draws costs no extra launch."""
         loc, tril_t = self._affine[sample_type]
+        if scale is not None:
+            key = (sample_type, tuple(scale))
+            if key not in self._affine:
+                sc = torch.tensor(scale, dtype=loc.dtype, device=loc.device)
+                self._affine[key] = ((loc * sc).contiguous(), (tril_t * sc[None, :]).contiguous())
+            loc, tril_t = self._affine[key]
         eps = torch.empty(n, loc.shape[1], dtype=loc.dtype, device=loc.device)
         for row in eps:
             row.normal_()                        # _standard_normal(event_shape) of one .sample() call

@@ -376,14 +376,16 @@ class Generator(nn.Module):
             i += 2
         return layers
 
-    def _batched_styles(self, lat):
+    def _batched_styles(self, lat, shared=None):
         """The 17 modulation linears (EqualLinear(style_dim, Cin), model.py:253) as one baddbmm per
         distinct Cin instead of 17 addmm launches forward and 34 backward.  Frozen G on the GPU
         only; returns per-latent-index entries: PreStyle lists are looked up by the caller through
-        _StyleRow."""
+        _StyleRow.  `shared` [B, style_dim]: the one w every layer receives (GAN2Shape's only case,
+        model.py:189-190, 207-210) — the batch of inputs is then an expanded view of it (no stack; the
+        backward is one sum per group instead of a stack, per-row selects and their accumulation)."""
         layers = self._style_layers()
         mods = [m.modulation for m, _ in layers]
-        if not lat[0].is_cuda or any(m.weight.requires_grad or m.bias.requires_grad for m in mods):
+        if shared is None and (not lat[0].is_cuda or not self._styles_frozen()):
             return _StyleRow(lat, None)
         key = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in mods)
         if getattr(self, '_style_key', None) != key:
@@ -399,11 +401,18 @@ class Generator(nn.Module):
             self._style_stacks, self._style_key = stacks, key
         pre = [None] * len(layers)
         for ns, w, b in self._style_stacks:
-            x = torch.stack([lat[layers[n][1]] for n in ns])        # [L, B, style_dim]
+            if shared is not None:
+                x = shared.unsqueeze(0).expand(len(ns), -1, -1)     # [L, B, style_dim], a view
+            else:
+                x = torch.stack([lat[layers[n][1]] for n in ns])    # [L, B, style_dim]
             s = torch.baddbmm(b, x, w).unbind(0)                     # L x [B, Cin]; one stack backward
             for j, n in enumerate(ns):
                 pre[n] = PreStyle(s[j])
         return _StyleRow(lat, pre)
+
+    def _styles_frozen(self):
+        return not any(m.modulation.weight.requires_grad or m.modulation.bias.requires_grad
+                       for m, _ in self._style_layers())
 
     def make_noise(self):
         """One [1,1,r,r] map per styled conv: 4, then two per octave up to `size` (model.py:468-477)."""
@@ -471,13 +480,17 @@ class Generator(nn.Module):
                 noise = [getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)]
         if truncation < 1:
             styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
-        latent = self._per_layer_latents(styles, inject_index)
-
-        out = self.input(latent)
-        # one unbind instead of 2 * n_latent selects: the backward is a single stack, not a
-        # zero-fill + copy + add per use (model.py:493-503 indexes latent[:, i] per layer)
-        lat = latent.unbind(1)
-        lat = self._batched_styles(lat)
+        shared = styles[0] if len(styles) == 1 and styles[0].dim() == 2 else None
+        if shared is not None and shared.is_cuda and self._styles_frozen():
+            latent = None                                  # built only if the caller asks for it
+            out = self.input(shared)
+            lat = self._batched_styles(None, shared)
+        else:
+            latent = self._per_layer_latents(styles, inject_index)
+            out = self.input(latent)
+            # one unbind instead of 2 * n_latent selects: the backward is a single stack, not a
+            # zero-fill + copy + add per use (model.py:493-503 indexes latent[:, i] per layer)
+            lat = self._batched_styles(latent.unbind(1))
         out = self.conv1(out, lat[0], noise=noise[0])
         skip = self.to_rgb1(out, lat[1])
         i = 1
@@ -493,7 +506,7 @@ class Generator(nn.Module):
         if return_features:
             return image, features
         if return_latents:
-            return image, latent
+            return image, latent if latent is not None else self._per_layer_latents(styles, inject_index)
         return image, None
 
 

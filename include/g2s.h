@@ -151,6 +151,12 @@ int g2s_maxpool2x2_bwd(const float *x, const float *gy, float *gx, int64_t plane
 int g2s_add_bias_scale(const float *a, const float *b, const float *bias, float *y, int64_t n, int64_t hw, int C,
                        float scale, g2s_stream_t stream);
 
+/* The mask pyramid of DiscriminatorLoss (GAN2Shape/losses.py:24-30): n_levels (1..4) successive
+ * avg_pool2d(., 2, 2) of x [planes, H, W] in one launch; levels: HOST array of n_levels device pointers,
+ * level l [planes, H / 2^(l+1), W / 2^(l+1)].  H, W multiples of 2^n_levels.  ATen's arithmetic per window. */
+int g2s_avg_pyramid(const float *x, float *const *levels, int n_levels, int64_t planes, int H, int W,
+                    g2s_stream_t stream);
+
 /* Entry of the offset encoder's residual block (GAN2Shape/networks.py:170-194): relu_out = relu(x) for the
  * residual path and pool_out = avg_pool2d(x, 2, 2) for the identity path in one pass over x [planes, H, W]
  * (H, W even); backward gx = g_relu * (x > 0) + g_pool / 4 in one pass (either gradient may be NULL). */

@@ -506,3 +506,37 @@ def test_modconv_demod_one_node_equals_two_nodes(L):
         lib.set_deterministic(False)
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("levels,shape", [(4, (8, 1, 128, 128)), (3, (2, 3, 32, 48)), (1, (1, 1, 2, 2))])
+def test_avg_pyramid_equals_successive_avg_pools(L, levels, shape):
+    import torch.nn.functional as F
+    from gan2shape_amd.losses import _mask_pyramid
+    g = torch.Generator().manual_seed(8)
+    m = torch.rand(*shape, generator=g).cuda()
+    got = _mask_pyramid(m, levels)
+    w = m
+    for l in range(levels):
+        w = F.avg_pool2d(w, 2, 2)
+        assert got[l].shape == w.shape and torch.equal(got[l], w), l
+
+
+def test_generator_shared_latent_path_equals_per_layer_latents():
+    """One w for every layer (GAN2Shape's only case): the modulations from an expanded view of it equal the
+    per-layer-latent route, values and the gradient that reaches w."""
+    from gan2shape_amd.stylegan2 import Generator
+    torch.manual_seed(3)
+    G = Generator(64, 512, 8, channel_multiplier=1).cuda().eval()
+    for p in G.parameters():
+        p.requires_grad_(False)
+    w = torch.randn(2, 512, device="cuda")
+    res = []
+    for shared in (True, False):
+        ww = w.clone().requires_grad_(True)
+        styles = [ww] if shared else [ww[:, None].expand(-1, G.n_latent, -1).contiguous()]
+        img, _ = G(styles, input_is_w=True, randomize_noise=False)
+        img.square().mean().backward()
+        res.append((img.detach(), ww.grad))
+    (i1, g1), (i0, g0) = res
+    assert float((i1 - i0).abs().max()) <= 1e-5 * float(i0.abs().max())
+    assert float((g1 - g0).norm() / g0.norm()) <= 1e-4
