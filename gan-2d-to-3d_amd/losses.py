@@ -4,6 +4,8 @@ kernel per direction (fused_geometry.smooth_loss)."""
 import torch
 import torch.nn.functional as F
 
+from . import zeropool
+
 
 def _weighted_mean(err, weight):
     """sum(err * w) / sum(w) with w broadcast to err; plain mean when w is None."""
@@ -24,7 +26,7 @@ class _WeightedL1(torch.autograd.Function):
         from . import lib as _lib
         x, y = x.contiguous(), y.contiguous()
         B, C, H, W = x.shape
-        numden = torch.zeros(2, dtype=torch.float32, device=x.device)   # numerator, mask.expand_as(err).sum()
+        numden = zeropool.zeros(2, x.device)   # numerator, mask.expand_as(err).sum()
         wc = None if w is None else w.contiguous()
         _lib.check(_lib.load().g2s_weighted_l1_fwd2(_lib.ptr(x), _lib.ptr(y), _lib.ptr(wc), _lib.ptr(numden), B, C,
                                                     H * W, _lib.stream()))
@@ -75,7 +77,7 @@ class _DFeatureL1(torch.autograd.Function):
         first = D.convs[0]
         y0 = first(x)
         blocks, out = [], y0
-        numden = torch.zeros(count, 2, dtype=torch.float32, device=x.device)   # per level: numerator, sum of weights
+        numden = zeropool.zeros((count, 2), x.device)   # per level: numerator, sum of weights
         for i in range(1, count + 1):
             blk = D.convs[i]
             in_hw = out.shape[2:]

@@ -15,6 +15,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from . import lib as _lib
+from . import zeropool
 
 # torchvision.models.vgg16().features layout: conv indices and the pools in front of each slice
 _VGG_SLICES = [
@@ -113,7 +114,7 @@ class _VggLpips(Function):
         sl = net.scaling_layer
         x = (torch.cat([pred, target], 0) - sl.shift) / sl.scale
         L = _lib.load()
-        acc = torch.zeros(N, dtype=torch.float32, device=pred.device)
+        acc = zeropool.zeros(N, pred.device)
         saved = []
         for si in range(5):
             entry = {"pool_in": None, "convs": []}
@@ -273,6 +274,8 @@ class PNetLin(nn.Module):
         with torch.no_grad():
             ft = self.net(self.scaling_layer(in0))
         fp = self.net(self.scaling_layer(in1))
+        # updated in place by _LpipsLayer: its own tensor (an in-place update of a pool slice would bump the
+        # version of every other view of the pool)
         acc = torch.zeros(in1.shape[0], dtype=torch.float32, device=in1.device)
         for k in range(5):
             acc = _LpipsLayer.apply(fp[k], ft[k], getattr(self, f"lin{k}").model[-1].weight, acc)

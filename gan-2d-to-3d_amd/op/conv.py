@@ -7,6 +7,7 @@ import torch
 from torch.autograd import Function
 
 from gan2shape_amd import lib as _lib
+from gan2shape_amd import zeropool
 
 
 class PassArena:
@@ -22,7 +23,8 @@ class PassArena:
 
     def __init__(self, device, fwd_elems):
         self.device = device
-        self.fwd = torch.zeros(fwd_elems, dtype=torch.float32, device=device) if fwd_elems else None
+        # inside a training step the arena is a slice of the step's cleared pool (zeropool.py): no fill of its own
+        self.fwd = zeropool.zeros(fwd_elems, device) if fwd_elems else None
         self.fwd_off = 0
         self.bwd_need = 0
         self.bwd = None
@@ -53,7 +55,7 @@ class PassArena:
         if n > self.LIMIT or self.bwd_need == 0:
             return None
         if self.bwd is None:  # first gradient of this pass: one clear for all of them
-            self.bwd = torch.zeros(self.bwd_need, dtype=torch.float32, device=self.device)
+            self.bwd = zeropool.zeros(self.bwd_need, self.device)
         if self.bwd_off + n > self.bwd.numel():
             return None       # e.g. a second backward through the same graph
         v = self.bwd[self.bwd_off:self.bwd_off + n].view(shape)

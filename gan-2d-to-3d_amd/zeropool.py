@@ -54,3 +54,14 @@ def take(shape, device):
         return None
     _state["off"] = off + _pad(n)
     return buf[off:off + n].view(shape)
+
+
+def zeros(shape, device):
+    """torch.zeros(shape) for a step-local accumulator: a slice of the step's pool when one is active (no
+    fill launch of its own), else a fresh cleared tensor.  Only for buffers that kernels fill through raw
+    pointers: an autograd-visible in-place op on a slice would bump the version counter all views of the
+    pool share."""
+    if isinstance(shape, int):
+        shape = (shape,)
+    t = take(tuple(shape), device)
+    return t if t is not None else torch.zeros(shape, dtype=torch.float32, device=device)
