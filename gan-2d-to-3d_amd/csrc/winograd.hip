@@ -532,6 +532,11 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
     bool partial_sums;
     const size_t y_floats = (size_t)B * M * H * W;
     bool use_part = false;
+    // Whole tiles over two or more rounds: 256 persistent workgroups walk consecutive tiles instead of the
+    // dispatcher starting `tiles` workgroups one round after the other (same arithmetic per tile; measured
+    // 2-6 % on the short-K launches, e.g. 18 x 64 -> 64 @ 128^2: 144 -> 136 us).
+    const bool whole = splitk == 1 || (splitk == 0 && (double)tiles / ((double)cdiv(tiles, NCU) * NCU) >= 0.9);
+    if (whole && tiles >= 2 * NCU) splitk = -10000 - NCU;
     if (splitk > 0) {
         splitk = std::min(splitk, d.ktiles);
         splitk = cdiv(d.ktiles, cdiv(d.ktiles, splitk));   // no empty slices
@@ -543,6 +548,14 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
             d.part = ws;
             d.part_n = (long)y_floats;
         }
+    } else if (splitk <= -10000) {
+        // persistent whole tiles: -splitk - 10000 workgroups, each a run of consecutive WHOLE tiles (a stream-K
+        // run length that is a multiple of the K tiles per tile: no partial sums, no reduce pass)
+        const int wgs = std::max(1, std::min(-splitk - 10000, tiles));
+        d.upw = d.ktiles * cdiv(tiles, wgs);
+        grid_x = cdiv(d.units, d.upw);
+        splitk = 1;
+        partial_sums = false;
     } else if (splitk < 0) {   // stream-K over -splitk workgroups (tests)
         d.upw = cdiv(d.units, std::min(-splitk, d.units));
         grid_x = cdiv(d.units, d.upw);
@@ -562,7 +575,7 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
     // stream-K with a workspace: every run stores its share of a split tile to a slot of its own
     // (at most ceil(ktiles / upw) + 1 runs meet in a tile) and wino_streamk_reduce_kernel finishes them
     bool streamk_part = false;
-    if (d.upw && ws && W % 2 == 0) {
+    if (d.upw && partial_sums && ws && W % 2 == 0) {
         const int slots = cdiv(d.ktiles, d.upw) + 1;
         if (slots <= SPLIT_REDUCE_MAX && (size_t)slots * y_floats <= (size_t)ws_floats) {
             streamk_part = use_part = true;

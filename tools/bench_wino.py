@@ -14,7 +14,11 @@ SIGS = [  # B, Cin, Cout, H  (G plain layers, D conv1, VGG at B = 9 and B = 2)
     (9, 64, 64, 128), (9, 64, 128, 64), (9, 128, 128, 64), (9, 128, 256, 32), (9, 256, 256, 32),
     (9, 256, 512, 16), (9, 512, 512, 16), (9, 512, 512, 8), (2, 64, 64, 128), (2, 128, 128, 64),
     (2, 256, 256, 32), (2, 512, 512, 16),
+    (18, 64, 64, 128), (18, 64, 128, 64), (18, 128, 128, 64), (18, 128, 256, 32), (18, 256, 256, 32),
+    (18, 256, 512, 16), (18, 512, 512, 16), (16, 128, 128, 128), (16, 256, 256, 64),
 ]
+if os.environ.get("G2S_WINO_SIGS") == "vgg":
+    SIGS = [s_ for s_ in SIGS if s_[0] in (9, 18, 16)]
 
 
 def timeit(fn, reps=30):
