@@ -61,6 +61,7 @@ struct WinoDesc {
     int ktiles, splitk;
     int upw;             // stream-K: K-tile units per workgroup (0 = one (tile, K slice) per workgroup)
     int units;           // stream-K: tiles * ktiles
+    int rr;              // persistent whole tiles over exactly 256 workgroups (see the kernel)
     int act;
     float act_alpha, act_gain;
     float *part;         // split-K with a workspace: slice s stores to part[s * part_n + offset in y]
@@ -88,7 +89,14 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
     int unit, unit_end;
     const int g = xcd_logical_tile();   // stream-K: index of this workgroup's run
     {
-        if (d.upw) {
+        if (d.rr) {
+            // 256 workgroups = 8 XCDs x 32 (g is XCD-major): XCD x owns the x-th eighth of the tiles — the chunk it
+            // gets in a plain launch — and its 32 workgroups walk that chunk side by side
+            const int tiles = d.units / d.ktiles, per_xcd = (tiles + 7) >> 3;
+            const int x = g >> 5, l = g & 31;
+            unit = (x * per_xcd + l) * d.ktiles;
+            unit_end = min(tiles, (x + 1) * per_xcd) * d.ktiles;
+        } else if (d.upw) {
             unit = g * d.upw;
             unit_end = min(d.units, unit + d.upw);
         } else {
@@ -111,6 +119,7 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
         const int kt_begin = unit - tile_id * d.ktiles;
         const int kt_end = min(d.ktiles, kt_begin + (unit_end - unit));
         unit += kt_end - kt_begin;
+        if (d.rr) unit += 31 * d.ktiles;   // the next tile of this workgroup's share: 32 tiles further on
         const int mt = tile_id % tiles_m, nt = tile_id / tiles_m;
         __syncthreads();   // the previous segment's LDS reads are done before this one's staging
         // ---- input patch of this thread: tile t = lane of the block, channel kc = wave of the K tile
@@ -549,11 +558,10 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
             d.part_n = (long)y_floats;
         }
     } else if (splitk <= -10000) {
-        // persistent whole tiles: -splitk - 10000 workgroups, each a run of consecutive WHOLE tiles (a stream-K
-        // run length that is a multiple of the K tiles per tile: no partial sums, no reduce pass)
-        const int wgs = std::max(1, std::min(-splitk - 10000, tiles));
-        d.upw = d.ktiles * cdiv(tiles, wgs);
-        grid_x = cdiv(d.units, d.upw);
+        // persistent whole tiles: 256 workgroups, each walking WHOLE tiles of its XCD's chunk (no partial sums, no
+        // reduce pass)
+        d.rr = 1;
+        grid_x = NCU;
         splitk = 1;
         partial_sums = false;
     } else if (splitk < 0) {   // stream-K over -splitk workgroups (tests)
