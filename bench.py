@@ -443,6 +443,8 @@ def main():
     cfg = face_config(args.n_proj, args.workload)
     if args.deterministic:
         cfg["deterministic"] = True
+    if os.environ.get("G2S_PARALLEL_NETS"):      # experiment switch: the two paired net passes
+        cfg["parallel_nets"] = True              # as two branches of the captured graph — measured 3 % slower
     trainer = Trainer(GAN2Shape, cfg, device=device, capturable=not args.eager)
     image, latent = synthetic_sample(trainer.model, 1234 + rank, device)
     torch.manual_seed(1234 + rank)

@@ -256,7 +256,8 @@ class GAN2Shape(nn.Module):
         outs[0] = jobs[0]()
         for out, side in zip(outs[1:], self._side_streams):
             main.wait_stream(side)
-            out.record_stream(main)
+            for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                t.record_stream(main)
         return outs
 
     # ------------------------------------------------------------------ step 1
@@ -278,12 +279,14 @@ class GAN2Shape(nn.Module):
 
         pre = kwargs.get('_nets')
         if pre is None and self.paired_nets:
-            depth_raw, albedo = networks.forward_pair(self.depth_net, self.albedo_net, images,
-                                                      train_a=not step1)
+            def vl_pair():
+                with self._no_grad_if(step1):
+                    return networks.forward_pair(self.viewpoint_net, self.lighting_net, images)
+            # the two paired passes read the same image and nothing else: two branches when parallel_nets is on
+            (depth_raw, albedo), (view, lighting) = self._fork([
+                lambda: networks.forward_pair(self.depth_net, self.albedo_net, images, train_a=not step1), vl_pair])
             if step1:
                 depth_raw = depth_raw.detach()
-            with self._no_grad_if(step1):
-                view, lighting = networks.forward_pair(self.viewpoint_net, self.lighting_net, images)
         elif pre is None:  # the four nets read the same image and nothing else: independent chains
             depth_raw, albedo, view, lighting = self._fork([
                 frozen_if_step1(self.depth_net, images), lambda: self.albedo_net(images),
@@ -445,8 +448,9 @@ class GAN2Shape(nn.Module):
         both = torch.cat([images[:1], projected_samples], 0) if len(images) == 1 else None
         if both is not None:
             if self.paired_nets:
-                depth_raw, albedo1 = networks.forward_pair(self.depth_net, self.albedo_net, images)
-                view_all, light_all = networks.forward_pair(self.viewpoint_net, self.lighting_net, both)
+                (depth_raw, albedo1), (view_all, light_all) = self._fork([
+                    lambda: networks.forward_pair(self.depth_net, self.albedo_net, images),
+                    lambda: networks.forward_pair(self.viewpoint_net, self.lighting_net, both)])
             else:
                 depth_raw, albedo1, view_all, light_all = self._fork([
                     lambda: self.depth_net(images), lambda: self.albedo_net(images),
