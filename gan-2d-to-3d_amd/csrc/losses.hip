@@ -63,14 +63,17 @@ __global__ __launch_bounds__(WL1_THREADS) void wl1_bwd(const float *__restrict__
 
 // The same with the denominator in the pass: numden[0] += sum |x - y| * w, numden[1] += sum w (over b, c, p — the
 // reference's mask.expand_as(err).sum(); w == NULL: the element count), so that the loss is one division away.
-__global__ __launch_bounds__(WL1_THREADS) void wl1_fwd2(const float *__restrict__ x, const float *__restrict__ y,
-                                                        const float *__restrict__ w, float *__restrict__ numden,
-                                                        int C, int HW4, long total4) {
-    __shared__ float sm[4];
+// THREADS = 256 in the default launch (many workgroups, float atomics); 1024 for the single workgroup of
+// deterministic mode (one fixed order; four times the loads in flight of a 256-thread one).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void wl1_fwd2(const float *__restrict__ x, const float *__restrict__ y,
+                                                    const float *__restrict__ w, float *__restrict__ numden,
+                                                    int C, int HW4, long total4) {
+    __shared__ float sm[2][THREADS / 64];
     float acc = 0.0f, wsum = 0.0f;
     const float4 *x4 = reinterpret_cast<const float4 *>(x), *y4 = reinterpret_cast<const float4 *>(y);
     const float4 *w4 = reinterpret_cast<const float4 *>(w);
-    for (long i = (long)blockIdx.x * WL1_THREADS + threadIdx.x; i < total4; i += (long)gridDim.x * WL1_THREADS) {
+    for (long i = (long)blockIdx.x * THREADS + threadIdx.x; i < total4; i += (long)gridDim.x * THREADS) {
         const float4 a = x4[i], b = y4[i];
         float4 m = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
         if (w) {
@@ -80,10 +83,22 @@ __global__ __launch_bounds__(WL1_THREADS) void wl1_fwd2(const float *__restrict_
         acc += (fabsf(a.x - b.x) * m.x + fabsf(a.y - b.y) * m.y) + (fabsf(a.z - b.z) * m.z + fabsf(a.w - b.w) * m.w);
         wsum += (m.x + m.y) + (m.z + m.w);
     }
-    const float s = wl1_block_sum(acc, sm);
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_down(acc, o, 64);
+        wsum += __shfl_down(wsum, o, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sm[0][wave] = acc;
+        sm[1][wave] = wsum;
+    }
     __syncthreads();
-    const float d = wl1_block_sum(wsum, sm);
     if (threadIdx.x == 0) {
+        float s = 0.0f, d = 0.0f;
+        for (int k = 0; k < THREADS / 64; k++) {   // fixed order
+            s += sm[0][k];
+            d += sm[1][k];
+        }
         unsafeAtomicAdd(numden, s);
         unsafeAtomicAdd(numden + 1, d);
     }
@@ -155,8 +170,12 @@ extern "C" int g2s_weighted_l1_fwd2(const float *x, const float *y, const float 
     if (rc) return rc;
     G2S_REQUIRE(numden, "numden must not be NULL (two ZEROED device floats: numerator, denominator)");
     const long total4 = (long)B * C * HW / 4;
-    const int blocks = deterministic() ? 1 : (int)std::min<long>(cdiv(total4, WL1_THREADS * 4), 2048);
-    wl1_fwd2<<<blocks, WL1_THREADS, 0, as_stream(stream)>>>(x, y, w, numden, C, HW / 4, total4);
+    if (deterministic()) {   // one workgroup strides over everything: the sums have one fixed order
+        wl1_fwd2<1024><<<1, 1024, 0, as_stream(stream)>>>(x, y, w, numden, C, HW / 4, total4);
+    } else {
+        const int blocks = (int)std::min<long>(cdiv(total4, WL1_THREADS * 4), 2048);
+        wl1_fwd2<WL1_THREADS><<<blocks, WL1_THREADS, 0, as_stream(stream)>>>(x, y, w, numden, C, HW / 4, total4);
+    }
     return check_launch("g2s_weighted_l1_fwd2");
 }
 
