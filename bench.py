@@ -108,6 +108,7 @@ class StepRunner:
             self.image, self.latent, src, n_proj_samples=t.n_proj_samples)
         loss.backward()
         optim.step()
+        sys.modules["gan2shape_amd.zeropool"].end()      # as the trainer does after every iteration
         if timed:
             e1.record()
             self.kind_ms[kind].append((e0, e1))

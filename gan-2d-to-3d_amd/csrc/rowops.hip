@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void demod_bwd(const float *__restrict__ wsq,
                                                  const float *__restrict__ s,
                                                  const float *__restrict__ demod,
                                                  const float *__restrict__ gd,
-                                                 const float *__restrict__ gs_add,
-                                                 float *__restrict__ gs, int B, int Cin, int Cout) {
+                                                 const float *gs_add,   // may alias gs (in-place add)
+                                                 float *gs, int B, int Cin, int Cout) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane, b = blockIdx.y;

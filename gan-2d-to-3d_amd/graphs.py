@@ -18,6 +18,8 @@ hand-offs — graph k+1 reads the output tensors of graph k in place.
 """
 import torch
 
+from . import zeropool
+
 
 class GraphedSteps:
     def __init__(self, trainer, image, latent, warmup=3):
@@ -41,6 +43,7 @@ class GraphedSteps:
             self.image, self.latent, src, n_proj_samples=self.t.n_proj_samples)
         loss.backward()
         optim.step()
+        zeropool.end()
         return loss, collected
 
     def _source(self, kind):

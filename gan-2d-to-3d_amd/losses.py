@@ -3,6 +3,7 @@ masked photometric L1, second-order smoothness.  On the GPU the smoothness loss 
 kernel per direction (fused_geometry.smooth_loss)."""
 import torch
 import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
 
 from . import zeropool
 
@@ -96,6 +97,7 @@ class _DFeatureL1(torch.autograd.Function):
         return (numden[:, 0] / numden[:, 1]).sum()
 
     @staticmethod
+    @once_differentiable        # the backward runs raw kernels on saved activations: no double backward
     def backward(ctx, g_total):
         from . import lib as _lib
         from .modconv import DOWN2, PLAIN, modconv_raw, relu_gate

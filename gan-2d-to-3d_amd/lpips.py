@@ -13,6 +13,7 @@ random-initialised (benchmarks / tests), and says so via `.pretrained`.
 import torch
 import torch.nn as nn
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from . import lib as _lib
 from . import zeropool
@@ -142,6 +143,7 @@ class _VggLpips(Function):
         return acc.view(-1, 1, 1, 1)
 
     @staticmethod
+    @once_differentiable        # the backward runs raw kernels on saved activations: no double backward
     def backward(ctx, gout):
         from .modconv import PLAIN, modconv_raw, relu_gate
         L = _lib.load()

@@ -53,6 +53,9 @@ def weighted_total(terms):
     key = (tuple(per_elem), flat[0].device)
     wv = _WSUM_CONST.get(key)
     if wv is None:
+        if flat[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            # a host-to-device upload cannot be captured: the eager warm-up iterations build every constant
+            raise RuntimeError("weighted_total: first use of this weight vector under graph capture; run the step eagerly once")
         if len(_WSUM_CONST) > 64:
             _WSUM_CONST.clear()
         wv = _WSUM_CONST[key] = torch.tensor([v for pe in per_elem for v in pe], dtype=torch.float32).to(flat[0].device)
@@ -268,8 +271,10 @@ class GAN2Shape(nn.Module):
         samples through V / L and through LPIPS; the arithmetic per sample is unchanged)."""
         b = 1
         h, w = self.image_size, self.image_size
-        if step1 and images.is_cuda:   # a step of its own (forward_step3 begins the pool for its inner call)
-            zeropool.begin("eval" if eval else 1, images.device)
+        if eval:
+            zeropool.end()      # evaluation is no training step: nothing of it is served from (or left in) a step's pool
+        elif step1 and images.is_cuda:   # a step of its own (forward_step3 begins the pool for its inner call)
+            zeropool.begin(1, images.device)
 
         def frozen_if_step1(net, x):  # model.py:99-122: only the albedo net learns in step 1
             def job():
@@ -397,10 +402,12 @@ class GAN2Shape(nn.Module):
             # a = l0/2 + .5, b = l1/2 + .5, direction = normalize(l2, l3, 1)): hand it the light vector
             # whose a and b are light_a + alpha * rand and light_b + rand
             from .fused_geometry import shading
-            if self._relight_consts is None:
-                self._relight_consts = torch.tensor([[2.0 * alpha, 2.0]], device=dev)
+            if self._relight_consts is None or self._relight_consts[0] != alpha:    # keyed on alpha: rand_light may change
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("sample_pseudo_imgs: constants for this rand_light are built eagerly; run step 2 once before capture")
+                self._relight_consts = (alpha, torch.tensor([[2.0 * alpha, 2.0]], device=dev))
             ab = torch.cat([light_a[:1].reshape(1, 1), light_b[:1].reshape(1, 1)], 1) * 2 - 1
-            light = torch.cat([ab + rand.view(-1, 1) * self._relight_consts, rand_light_dxy], 1)
+            light = torch.cat([ab + rand.view(-1, 1) * self._relight_consts[1], rand_light_dxy], 1)
             _, rand_light_im = shading(normal[:1], light, albedo[:1])
         else:
             rand_light_d = torch.cat([rand_light_dxy, torch.ones(n_images, 1, device=dev)], 1)

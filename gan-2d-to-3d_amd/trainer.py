@@ -17,6 +17,7 @@ import logging
 import torch
 from torch.utils.data import DataLoader, Subset
 
+from . import zeropool
 from .priors import PriorGenerator
 from .sharding import shard_indices  # noqa: F401  (re-exported)
 
@@ -92,6 +93,7 @@ class Trainer():
                                                   n_proj_samples=self.n_proj_samples)
                         loss.backward()
                         optim.step()
+                        zeropool.end()       # the step's cleared pool serves nothing beyond the step
                         total_it += 1
                     self.history.append((data_index, stage, step,
                                          None if loss is None else float(loss.detach())))
@@ -157,6 +159,7 @@ class Trainer():
         from .sharding import allreduce_mean_gradients
         allreduce_mean_gradients([p for g in optim.param_groups for p in g['params']])
         optim.step()
+        zeropool.end()
 
     @staticmethod
     def default_optimizer(model_list, lr=1e-4, betas=(0.9, 0.999), weight_decay=5e-4,

@@ -5,13 +5,13 @@ the polyphase classes that leave holes add into an output that must start at zer
 clears such an output itself (hipMemsetAsync) — one more graph node per launch, 36 of step 1's 319.
 Here each step kind clears ONE buffer at its start and hands out slices (g2s_modconv_ex,
 y_is_zero = 1).  The buffer is a fresh tensor of the caching allocator per step (sized by what the
-previous step of that kind asked for), slices are ordinary views that keep it alive, nothing is ever
-handed out twice: no lifetime hazards, and inside a captured HIP graph it lives in the graph's
+previous step of that kind asked for), slices are tensors on its storage (they keep it alive; each has its
+own autograd version counter), nothing is ever handed out twice: no lifetime hazards, and inside a captured HIP graph it lives in the graph's
 private pool like every other tensor of the step.  A request that does not fit falls back to the
 library's own clear."""
 import torch
 
-_state = {"buf": None, "off": 0, "key": None}
+_state = {"buf": None, "off": 0, "key": None, "capturing": False}
 _demand = {}          # step kind -> floats requested during the last step of that kind
 _want = {}            # running count of the current step
 
@@ -29,14 +29,22 @@ def begin(key, device):
     n = _demand.get(key, 0)
     _state["key"] = key
     _state["off"] = 0
+    _state["capturing"] = _capturing(device)
     _state["buf"] = torch.zeros(n, dtype=torch.float32, device=device) if n else None
 
 
+def _capturing(device):
+    return torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+
 def end():
+    """End of the step (the trainers call it after backward + optimiser step, forward_step1(eval=True) before
+    it returns): nothing outside a step is ever served from a step's pool — in particular not from a pool that
+    lives in a captured graph's private memory, which every replay clears again."""
     cur = _state["key"]
     if cur is not None:
         _demand[cur] = _want.get(cur, 0)
-    _state.update(buf=None, off=0, key=None)
+    _state.update(buf=None, off=0, key=None, capturing=False)
 
 
 def take(shape, device):
@@ -52,15 +60,18 @@ def take(shape, device):
     buf, off = _state["buf"], _state["off"]
     if buf is None or buf.device != device or off + n > buf.numel():
         return None
+    if _capturing(device) != _state["capturing"]:
+        return None     # a pool begun under capture is graph memory (and vice versa): never hand it across
     _state["off"] = off + _pad(n)
-    return buf[off:off + n].view(shape)
+    # a tensor of its own on the pool's storage, NOT a view of `buf`: views share one version counter, so an
+    # autograd-visible in-place op on one slice would invalidate every saved slice of the step
+    return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(buf.untyped_storage(), buf.storage_offset() + off,
+                                                                   tuple(int(d) for d in shape))
 
 
 def zeros(shape, device):
     """torch.zeros(shape) for a step-local accumulator: a slice of the step's pool when one is active (no
-    fill launch of its own), else a fresh cleared tensor.  Only for buffers that kernels fill through raw
-    pointers: an autograd-visible in-place op on a slice would bump the version counter all views of the
-    pool share."""
+    fill launch of its own), else a fresh cleared tensor."""
     if isinstance(shape, int):
         shape = (shape,)
     t = take(tuple(shape), device)

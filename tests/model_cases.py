@@ -154,22 +154,37 @@ class capture_step_tensors:
     (renderer.warp_canon_depth, renderer.py:116-125), each with `retain_grad()` so that after
     backward() `.grad` holds d loss / d tensor.  Lists are in call order."""
 
-    def __init__(self, model):
+    def __init__(self, model, kink_masks=None):
         self.m, self.view, self.depth, self.recon_depth, self.verts = model, [], [], [], []
+        # every inverse-warp sampling grid (renderer.get_inv_warped_2d_grid, renderer.py:109-113), in call
+        # order; with `kink_masks` (one bool array [B, H, W] per call) the gradient that reaches the grid is
+        # zeroed at the masked pixels — see grid_kinks()
+        self.grid, self.kink_masks = [], kink_masks
 
     def __enter__(self):
         m = self.m
         view_fn = "_set_view" if hasattr(m, "_set_view") else "get_view_transformation"
         self._orig = [(m, view_fn, getattr(m, view_fn)), (m, "get_clamped_depth", m.get_clamped_depth),
                       (m.renderer, "warp_canon_depth", m.renderer.warp_canon_depth),
-                      (m.renderer, "get_warped_3d_grid", m.renderer.get_warped_3d_grid)]
+                      (m.renderer, "get_warped_3d_grid", m.renderer.get_warped_3d_grid),
+                      (m.renderer, "get_inv_warped_2d_grid", m.renderer.get_inv_warped_2d_grid)]
 
         def keep(t, where):
             if t.requires_grad:
                 t.retain_grad()
             where.append(t)
             return t
-        (_, _, view0), (_, _, clamp0), (_, _, warp0), (_, _, verts0) = self._orig
+        (_, _, view0), (_, _, clamp0), (_, _, warp0), (_, _, verts0), (_, _, grid0) = self._orig
+
+        def grid_fn(*a, **k):
+            grid = grid0(*a, **k)
+            if self.kink_masks is not None and grid.requires_grad:
+                mask = torch.as_tensor(self.kink_masks[len(self.grid)], device=grid.device)
+                assert mask.shape == grid.shape[:3], (mask.shape, grid.shape)
+                grid.register_hook(lambda gg, mask=mask: gg.masked_fill(mask.unsqueeze(-1), 0.0))
+            self.grid.append(grid)
+            return grid
+        m.renderer.get_inv_warped_2d_grid = grid_fn
         setattr(m, view_fn, lambda view, *a, **k: view0(keep(view, self.view), *a, **k))
         m.get_clamped_depth = lambda *a, **k: keep(clamp0(*a, **k), self.depth)
         m.renderer.warp_canon_depth = lambda *a, **k: keep(warp0(*a, **k), self.recon_depth)
@@ -299,3 +314,70 @@ def toy_dataset(n=2):
 
 TOY_STAGES = [{'step1': 2, 'step2': 1, 'step3': 2}, {'step1': 1, 'step2': 3, 'step3': 1}]
 TOY_CFG = {"image_size": 8, "category": "face", "n_proj_samples": 3, "n_epochs_prior": 2, "prior_name": "ellipsoid"}
+
+
+# ---- directional gradient evidence of a whole step (steps.npz `*.gproj.*`, `*.gtnorm.*`)
+N_PROBES = 6
+
+
+def probe_direction(n, k):
+    """Probe direction k over a flat parameter vector of n entries: a fixed integer hash of (index, k)
+    mapped to [-1, 1) — pure integer arithmetic, so make_golden (reference side) and the tests (this
+    package's side) build bit-identical float64 vectors on any machine without storing them."""
+    import numpy as np
+    i = np.arange(n, dtype=np.uint64)
+    h = i + np.uint64((0x9E3779B97F4A7C15 * (k + 1)) & 0xFFFFFFFFFFFFFFFF)    # uint64 array arithmetic wraps
+    h ^= h >> np.uint64(30)
+    h = h * np.uint64(0xBF58476D1CE4E5B9)
+    h ^= h >> np.uint64(27)
+    h = h * np.uint64(0x94D049BB133111EB)
+    h ^= h >> np.uint64(31)
+    return (h >> np.uint64(11)).astype(np.float64) / float(1 << 52) - 1.0
+
+
+def grad_evidence(net):
+    """(per-tensor gradient norms, <grad, r_k> for the N_PROBES probe directions), both float64 numpy,
+    over the net's parameters in SORTED NAME order (the reference's nets and this package's are
+    state-dict compatible; a parameter without gradient counts as zeros).  A sign flip, a permutation of
+    elements within a tensor or of tensors, or a wrong scale of one tensor changes these numbers; one
+    scalar norm per net does not see the first two."""
+    import numpy as np
+    named = sorted(net.named_parameters(), key=lambda kv: kv[0])
+    grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).detach().double().reshape(-1).cpu() for _, p in named]
+    tnorm = np.array([float(g.norm()) for g in grads])
+    flat = torch.cat(grads).numpy()
+    proj = np.array([float(flat @ probe_direction(flat.size, k)) for k in range(N_PROBES)])
+    return tnorm, proj
+
+
+SMOOTH_DEPTH_GAIN = 0.03
+
+
+def smooth_depth_net(net, gain=SMOOTH_DEPTH_GAIN):
+    """Scale the depth net's last convolution (networks.py:133: Conv2d(nf, 1, 5), no activation) in place:
+    the relief of the canonical depth shrinks from the whole tanh range to a few 1e-3 around the mean — a
+    surface the +-few-degree views of the step fixtures cannot fold (steps.npz `s3s.*`)."""
+    convs = [(name, p) for name, p in net.named_parameters() if p.dim() == 4]
+    name, last = max(convs, key=lambda kv: int(kv[0].split(".")[1]))
+    assert last.shape[0] == 1, (name, last.shape)
+    with torch.no_grad():
+        last.mul_(gain)
+
+
+KINK_TOL = 2e-3      # pixels
+
+
+def grid_kinks(grid, tol=KINK_TOL):
+    """Pixels of a sampling grid [B, H, W, 2] (normalised coordinates, align_corners=True: texel i sits at
+    -1 + 2 i / (W - 1)) whose position lies within `tol` pixels of a texel row or column: there
+    F.grid_sample's gradient with respect to the POSITION jumps from one bilinear cell's slope to the next
+    one's, so which slope a sample within fp32 rounding of the border takes is decided by the last bit of
+    the chain depth -> 3-D point -> rotation -> projection.  Positions are spread evenly, so a fraction
+    ~4 tol of all samples qualifies whatever the scene (0.8 % at 2e-3): a conditioned fixture masks them
+    a priori, from the reference run's own positions, on both sides."""
+    import numpy as np
+    g = grid.detach().double().cpu().numpy()
+    H, W = g.shape[1:3]
+    px = (g[..., 0] + 1) / 2 * (W - 1)
+    py = (g[..., 1] + 1) / 2 * (H - 1)
+    return (np.abs(px - np.round(px)) < tol) | (np.abs(py - np.round(py)) < tol)

@@ -138,48 +138,8 @@ def test_clamp_matches_torch_including_the_bounds(L):
     assert torch.equal(y.detach(), x.detach().clamp(-0.5, 0.25))
 
 
-def test_every_step_kind_actually_optimises():
-    """End-to-end sanity of the gradients in aggregate (complements the per-tensor fixtures): the prior
-    pre-training of the depth net (trainer.py:130-161) fits the prior, step 1 lowers its loss under its
-    own Adam, steps 2 and 3 run 25 updates each with finite, bounded losses.  Fresh model, eager steps."""
-    import bench
-    from gan2shape_amd.model import GAN2Shape
-    from gan2shape_amd.trainer import Trainer
-    torch.manual_seed(0)
-    cfg = bench.face_config(n_proj=4)
-    cfg["n_epochs_prior"] = 60
-    cfg["learning_rate"] = 1e-3          # steps 1 / 2: the reference's 1e-4 moves too little in 25 iterations to assert on
-    t = Trainer(GAN2Shape, cfg, device="cuda")
-    image, latent = bench.synthetic_sample(t.model, 4321, torch.device("cuda"))
-    prior_losses = t.pretrain_on_prior(image, 0)
-    assert len(prior_losses) == 60 and prior_losses[-1] < 0.2 * prior_losses[0], (prior_losses[0], prior_losses[-1])
-
-    m = t.model
-    collected = None
-    # step 3 moves the pose: at 10x the reference's rate a view can leave the frame within a few updates
-    # (empty mask -> 0 / 0 in the masked losses, in the reference alike): it keeps the reference's 1e-4
-    for group in t.optim_step3.param_groups:
-        group["lr"] = 1e-4
-    for step, n_it in ((1, 25), (2, 25), (3, 25)):
-        optim = getattr(t, f"optim_step{step}")
-        forward = getattr(m, f"forward_step{step}")
-        torch.manual_seed(100 + step)
-        losses = []
-        out = None
-        for it in range(n_it):
-            if step == 2:
-                torch.manual_seed(7)         # the same pseudo views / lights every iteration: one objective
-            optim.zero_grad()
-            loss, out = forward(image, latent, collected, n_proj_samples=4)
-            loss.backward()
-            optim.step()
-            losses.append(float(loss.detach()))
-        collected = out
-        assert all(np.isfinite(losses)), (step, losses)
-        head, tail = np.mean(losses[:3]), np.mean(losses[-3:])
-        # step 1 (albedo against a fixed target) descends smoothly; steps 2 / 3 re-render through nets that
-        # move under them (loss fluctuates +-5 % from one iteration to the next): they must stay bounded
-        assert tail < (0.97 if step == 1 else 1.25) * head, (step, head, tail, losses)
+# test_every_step_kind_actually_optimises moved to tests/test_gpu_round4.py (test_every_step_kind_lowers_its_own_loss:
+# real descent bounds at the reference's learning rate; the cause of round 3's red run is recorded there)
 
 
 @pytest.mark.parametrize("masked", [True, False])

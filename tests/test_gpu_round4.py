@@ -1,0 +1,193 @@
+"""Round-4 GPU tests: whole-step gradients against central differences of the loss, and the descent
+assertions that round 3 had relaxed (ADVICE tests/test_gpu_round3.py:182)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N_PROJ = 4
+
+
+@pytest.fixture(scope="module")
+def g2s():
+    import gan2shape_amd  # noqa: F401
+    from gan2shape_amd import lib
+    lib.load()
+    return gan2shape_amd
+
+
+@pytest.fixture(scope="module")
+def scenario(g2s):
+    """The set-up of round 3's optimisation test: fresh model (seed 0), 60 iterations of prior pre-training,
+    25 iterations of step 1 at lr 1e-3, then the hand-offs of one (untrained) step-2 forward."""
+    import bench
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import Trainer
+    torch.manual_seed(0)
+    cfg = bench.face_config(n_proj=N_PROJ)
+    cfg["n_epochs_prior"] = 60
+    cfg["learning_rate"] = 1e-3          # step 1 only (see below): the reference's 1e-4 moves the albedo net too little in 25 iterations
+    t = Trainer(GAN2Shape, cfg, device="cuda")
+    image, latent = bench.synthetic_sample(t.model, 4321, torch.device("cuda"))
+    prior_losses = t.pretrain_on_prior(image, 0)
+    m = t.model
+    torch.manual_seed(101)
+    losses1, out = [], None
+    for _ in range(25):
+        t.optim_step1.zero_grad()
+        loss, out = m.forward_step1(image, latent, None, n_proj_samples=N_PROJ)
+        loss.backward()
+        t.optim_step1.step()
+        losses1.append(float(loss.detach()))
+    collected = {2: out}
+    torch.manual_seed(7)
+    with torch.no_grad():
+        _, collected[3] = m.forward_step2(image, latent, out, n_proj_samples=N_PROJ)
+    return dict(t=t, m=m, image=image, latent=latent, collected=collected, prior=prior_losses, step1=losses1)
+
+
+def _params(t, step):
+    return [p for group in getattr(t, f"optim_step{step}").param_groups for p in group["params"]]
+
+
+def _flat(ts):
+    return torch.cat([x.reshape(-1) for x in ts])
+
+
+def _set(ps, vec):
+    off = 0
+    with torch.no_grad():
+        for p in ps:
+            p.copy_(vec[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+
+def _evaluate(sc, step, grad):
+    """Loss (and flat float64 gradient) of the FIXED objective of a step: the random draws of step 2 are
+    re-seeded before every evaluation."""
+    m, ps = sc["m"], _params(sc["t"], step)
+    torch.manual_seed(7)
+    for p in ps:
+        p.grad = None
+    with torch.enable_grad() if grad else torch.no_grad():
+        loss, _ = getattr(m, f"forward_step{step}")(sc["image"], sc["latent"], sc["collected"][step], n_proj_samples=N_PROJ)
+        if not grad:
+            return float(loss)
+        loss.backward()
+    g = _flat([p.grad if p.grad is not None else torch.zeros_like(p) for p in ps]).double()
+    for p in ps:
+        p.grad = None
+    return float(loss.detach()), g
+
+
+@pytest.mark.parametrize("step", [2, 3])
+def test_step_gradient_is_the_directional_derivative_of_the_loss(scenario, step):
+    """(L(theta + eps d) - L(theta - eps d)) / (2 eps) against <g, d> through forward_step2 / forward_step3 as the
+    trainer runs them — the product path: discriminator-feature loss and LPIPS as single autograd nodes with
+    hand-written backward passes (losses._DFeatureL1, lpips._VggLpips), demodulated convolutions as one node
+    (modconv.ModConvDemodFunction), every kernel's analytic backward.  Directions: d = g / |g| (the whole gradient:
+    the difference quotient must return |g|) and g restricted to each parameter group — step 3: each of the four
+    nets; step 2: thirds of the encoder's tensor list —, so a wrong gradient in ONE net or layer range cannot hide
+    in the norm of the rest.  fp32 window measured with tools/dirderiv.py (gpurun_out/r4_dirderiv.log): at eps =
+    3e-4 the quotient along g / |g| is 0.2 - 0.3 % below <g, d> (curvature) and the loss repeats to 1.4e-6
+    (2.4e-3 on the quotient).  Also: the gradient of the op-by-op autograd path (ONE_NODE off) equals the
+    product's (measured 4.6e-4 / 3.6e-4 of its norm, cosine 0.9999999)."""
+    from gan2shape_amd import lib, losses, lpips
+    sc = scenario
+    ps = _params(sc["t"], step)
+    theta0 = _flat([p.detach() for p in ps]).clone()
+    # step 3 in deterministic mode: in the default mode its gradient scatters by 6e-3 from run to run (float-atomic
+    # noise in the nets' forward decides supersamples on fold edges) — the loss itself does not
+    prev = lib.set_deterministic(step == 3)
+    try:
+        loss0, g = _evaluate(sc, step, True)
+        try:
+            losses.DiscriminatorLoss.ONE_NODE = lpips.PNetLin.ONE_NODE = False
+            _, g_ops = _evaluate(sc, step, True)
+        finally:
+            losses.DiscriminatorLoss.ONE_NODE = lpips.PNetLin.ONE_NODE = True
+        cos = float(g @ g_ops / (g.norm() * g_ops.norm()))
+        rel = float((g - g_ops).norm() / g_ops.norm())
+        print(f"[step {step}] loss {loss0:.6f} |g| {float(g.norm()):.5e}; product vs op-by-op: cosine {cos:.8f}, rel diff {rel:.2e}")
+        assert cos >= 0.999999 and rel <= 2e-3, (cos, rel)
+
+        sizes = [p.numel() for p in ps]
+        if step == 3:
+            m = sc["m"]
+            groups = {}
+            for name in ("lighting", "viewpoint", "depth", "albedo"):
+                ids = {id(p) for p in getattr(m, f"{name}_net").parameters()}
+                groups[name] = [id(p) in ids for p in ps]
+        else:
+            third = (len(ps) + 2) // 3
+            groups = {f"tensors {i * third}..{min(len(ps), (i + 1) * third) - 1}": [i * third <= j < (i + 1) * third for j in range(len(ps))]
+                      for i in range(3)}
+        dirs = {"g / |g|": g / g.norm()}
+        for name, sel in groups.items():
+            mask = torch.cat([torch.full((n,), float(s_), dtype=torch.float64, device=g.device) for n, s_ in zip(sizes, sel)])
+            d = g * mask
+            assert float(d.norm()) > 0, name
+            dirs[name] = d / d.norm()
+        eps = 3e-4 if step == 2 else 1e-4      # step 3's loss repeats to 1e-7 (deterministic mode): a smaller step, less curvature
+        for name, d in dirs.items():
+            want = float(g @ d)
+            _set(ps, (theta0.double() + eps * d).float())
+            lp_ = _evaluate(sc, step, False)
+            _set(ps, (theta0.double() - eps * d).float())
+            lm_ = _evaluate(sc, step, False)
+            got = (lp_ - lm_) / (2 * eps)
+            print(f"[step {step}] {name:18s} <g, d> = {want:.5e}   central difference = {got:.5e}   ({got / want - 1:+.2%})")
+            assert abs(got - want) <= 2e-2 * abs(want) + 6e-3, (step, name, want, got)
+    finally:
+        _set(ps, theta0)
+        lib.set_deterministic(prev)
+
+
+def test_every_step_kind_lowers_its_own_loss(scenario):
+    """The descent assertion round 3 had relaxed to `tail < 1.25 * head`, restored.
+
+    CAUSE of the red run (gpurun_out/r3_gpu_tests_11_1.log: step 2's loss 3.31 -> 3.51 over 25 updates on a fixed
+    objective), established with tools/dirderiv.py and tools/descent_curves.py (gpurun_out/r4_dirderiv*.log,
+    r4_descent_{old,new}.log): not the gradient — the test above holds it to central differences, and
+    the hand-written backward equals autograd's op-by-op chain to 5e-4 — but the test's step size.  It ran the
+    offset encoder at lr 1e-3, 10x the reference's (trainer.py:163-171): Adam's first updates are sign-like steps
+    of |d theta| ~ lr * sqrt(P) = 3.7 on a parameter vector of norm 38.6 (P = 13.8 M), 700x the radius (~5e-3) in
+    which a line search finds the loss linear.  The trajectory is chaotic: float-atomic noise of 1e-7 separates
+    two runs within three iterations, and spikes to 4.0 .. 6.1 appear at random iterations in 4 of 12 runs — in
+    the one-node and the op-by-op form alike, on the tree of commit 2519979 and on today's.  All 12 runs still
+    descend over 25 iterations (tails 1.8 .. 2.9 from 3.3) unless a spike falls into the last three.  At the
+    reference's lr 1e-4 both torch.optim.Adam and g2s_adam_step descend smoothly (3.375 -> 1.77 after 25, 1.02
+    after 60 iterations; step 3: 1.379 -> 0.81 after 25).
+
+    So: step 1 at lr 1e-3 as before (the albedo net against a fixed target: smooth), steps 2 and 3 at the
+    reference's 1e-4 on their fixed objectives with real descent bounds (measured: step 2 3.31 -> 1.60 in 30 iterations, ratio
+    0.48; step 3, started from that trained encoder's samples, 0.862 -> 0.721 in 25, ratio 0.86, monotone)."""
+    sc = scenario
+    t, m = sc["t"], sc["m"]
+    assert len(sc["prior"]) == 60 and sc["prior"][-1] < 0.2 * sc["prior"][0], (sc["prior"][0], sc["prior"][-1])
+    l1 = sc["step1"]
+    assert np.mean(l1[-3:]) < 0.97 * np.mean(l1[:3]), l1
+    collected = sc["collected"][2]
+    for step, n_it, bound in ((2, 30, 0.70), (3, 25, 0.92)):
+        optim = getattr(t, f"optim_step{step}")
+        for group in optim.param_groups:
+            group["lr"] = 1e-4
+        forward = getattr(m, f"forward_step{step}")
+        curve, out = [], None
+        for _ in range(n_it):
+            torch.manual_seed(7)             # step 2: the same pseudo views / lights every iteration: one objective
+            optim.zero_grad()
+            loss, out = forward(sc["image"], sc["latent"], collected, n_proj_samples=N_PROJ)
+            loss.backward()
+            optim.step()
+            curve.append(float(loss.detach()))
+        collected = out
+        assert all(np.isfinite(curve)), (step, curve)
+        head, tail = np.mean(curve[:3]), np.mean(curve[-3:])
+        print(f"[descent] step {step}: head {head:.4f} tail {tail:.4f} ratio {tail / head:.3f} | " + " ".join(f"{v:.3f}" for v in curve))
+        assert tail < bound * head, (step, head, tail, curve)
+        # and no update overshoots: at the reference's step size the curve never rises above its start, and
+        # (measured: step 2 falls with 3 - 5 small upticks in 30 iterations, step 3 monotonically) most updates lower it
+        assert max(curve) <= 1.02 * curve[0], (step, curve)
+        assert np.mean(np.diff(curve) < 0) >= 0.7, (step, curve)
