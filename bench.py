@@ -51,14 +51,22 @@ WORKLOADS = {
     "face256_fp16": dict(image_size=256, gan_size=256, prior_name='confidence', mfma_operands='f16', dtype="f16"),
     # the same workload on the fp32 kernels (direct + Winograd): the line the fp16 path has to beat
     "face256_f32": dict(image_size=256, gan_size=256, prior_name='confidence', mfma_operands='f32', dtype="f32"),
+    # BASELINE.json configs[3]: configs/car.yml (gan_size 512, channel_multiplier 2, 8 projected samples) at 128x128
+    # under JOINT training (GeneralizingTrainer2, trainer.py:338-479; main.py:141 step mix 13:22:18): one shared
+    # model, one image per rank and iteration, ONE flat-bucket gradient all-reduce (mean) per optimiser step
+    "car128_joint": dict(image_size=128, gan_size=512, channel_multiplier=2, prior_name='ellipsoid', mfma_operands='f32',
+                         dtype="f32", joint=True),
 }
+JOINT_PATTERN = [1] * 13 + [2] * 22 + [3] * 18      # main.py:141: stages = [{'step1': 13, 'step2': 22, 'step3': 18}]
 
 
 def face_config(n_proj=8, workload="face128_n8"):
     wl = WORKLOADS[workload]
     cfg = _face_config(n_proj)
     cfg.update(image_size=wl["image_size"], gan_size=wl["gan_size"], prior_name=wl["prior_name"],
-               mfma_operands=wl["mfma_operands"])
+               mfma_operands=wl["mfma_operands"], channel_multiplier=wl.get("channel_multiplier", 1))
+    if wl.get("joint"):
+        cfg["category"] = "car"
     return cfg
 
 
@@ -115,6 +123,55 @@ class StepRunner:
         self.collected[kind] = collected
         self.last_loss[kind] = loss.detach()
         return loss
+
+
+class JointStepRunner(StepRunner):
+    """Joint (data-parallel) iterations as GeneralizingTrainer2.fit runs them (trainer.py:338-479 semantics):
+    every optimiser step is preceded by ONE all-reduce (mean) of the optimiser's persistent flat gradient
+    bucket (sharding.GradBucket) — a single process packs and binds the same bucket without the collective,
+    so the N = 1 line measures the path the N > 1 ranks run; step 1 centres the depth over all ranks' images."""
+
+    def __init__(self, trainer, image, latent, world):
+        super().__init__(trainer, image, latent)
+        from gan2shape_amd import sharding
+        self.world, self.sh = world, sharding
+
+    def run(self, kind, timed=False):
+        t = self.t
+        optim = getattr(t, f'optim_step{kind}')
+        src = {1: None, 2: self.collected[1], 3: self.collected[2]}[kind]
+        t.model.batch_mean = self.sh.global_mean if (kind == 1 and self.world > 1) else None
+        optim.zero_grad()
+        loss, collected = getattr(t.model, f'forward_step{kind}')(
+            self.image, self.latent, src, n_proj_samples=t.n_proj_samples)
+        loss.backward()
+        t.model.batch_mean = None
+        bucket = self.sh.bucket_of([p for g in optim.param_groups for p in g['params']])
+        bucket.pack()
+        bucket.all_reduce_mean()
+        bucket.bind()
+        optim.step()
+        sys.modules["gan2shape_amd.zeropool"].end()
+        self.collected[kind] = collected
+        self.last_loss[kind] = loss.detach()
+        return loss
+
+
+class GraphedJointRunner:
+    """Steps 2 / 3 (and step 1 of a single process) as two replayed graph segments around the collective
+    (graphs.GraphedJointSteps); step 1 of W > 1 ranks holds a collective in its forward and runs eagerly."""
+
+    def __init__(self, graphed, eager, world):
+        self.g, self.eager, self.world = graphed, eager, world
+        self.kind_ms = {1: [], 2: [], 3: []}
+        self.last_loss = graphed.loss
+
+    def run(self, kind, timed=False):
+        if kind == 1 and self.world > 1:
+            loss = self.eager.run(1)
+            self.g.loss[1] = loss.detach()
+            return loss
+        return self.g.run(kind)
 
 
 class GraphedRunner:
@@ -420,6 +477,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))   # before anything in this process touches the GPU
     global PATTERN
+    joint = bool(WORKLOADS[args.workload].get("joint"))
+    if joint:
+        PATTERN = list(JOINT_PATTERN)
     if args.only:
         PATTERN = [args.only]
     import gan2shape_amd  # noqa: F401
@@ -437,7 +497,7 @@ def main():
 
     from gan2shape_amd import lib, modconv as mc
     from gan2shape_amd.model import GAN2Shape
-    from gan2shape_amd.trainer import Trainer
+    from gan2shape_amd.trainer import GeneralizingTrainer2, Trainer
     lib.load()
 
     torch.manual_seed(0)  # identical random-init weights on every rank
@@ -446,10 +506,10 @@ def main():
         cfg["deterministic"] = True
     if os.environ.get("G2S_PARALLEL_NETS"):      # experiment switch: the two paired net passes
         cfg["parallel_nets"] = True              # as two branches of the captured graph — measured 3 % slower
-    trainer = Trainer(GAN2Shape, cfg, device=device, capturable=not args.eager)
+    trainer = (GeneralizingTrainer2 if joint else Trainer)(GAN2Shape, cfg, device=device, capturable=not args.eager)
     image, latent = synthetic_sample(trainer.model, 1234 + rank, device)
     torch.manual_seed(1234 + rank)
-    runner = StepRunner(trainer, image, latent)
+    runner = JointStepRunner(trainer, image, latent, world) if joint else StepRunner(trainer, image, latent)
 
     # setup pass (not a benchmark step): one iteration of each kind creates the `collected`
     # hand-offs the trainer would have at this point, and triggers lazy library initialisation
@@ -458,13 +518,16 @@ def main():
     eager_runner = runner
     if not args.eager:
         # record each step kind into a HIP graph; a replay is one training iteration
-        from gan2shape_amd.graphs import GraphedSteps
-        graphed = GraphedSteps(trainer, image, latent)
+        from gan2shape_amd.graphs import GraphedJointSteps, GraphedSteps
+        graphed = (GraphedJointSteps if joint else GraphedSteps)(trainer, image, latent)
         graphed.collected = dict(runner.collected)
         for kind in (1, 2, 3):
+            if joint and kind == 1 and world > 1:
+                graphed.loss[1] = runner.last_loss[1]       # eager (collective in the forward): GraphedJointRunner
+                continue
             graphed.capture(kind)
             graphed.run(kind)   # a capture only records: one replay fills the hand-off buffers
-        runner = GraphedRunner(graphed)
+        runner = GraphedJointRunner(graphed, eager_runner, world) if joint else GraphedRunner(graphed)
     for i in range(args.warmup):
         runner.run(PATTERN[i % len(PATTERN)])
 
@@ -550,8 +613,23 @@ def main():
                                     "achieved": sum(p[0] for p, _ in sel) / (tk * 1e-3) / 1e12,
                                     "mfma_executed": sum(p[4] for p, _ in sel) / (tk * 1e-3) / 1e12,
                                     "avg_launch_us": tk * 1e3 / len(sel)}
-        traffic, traffic_src = None, None
+        # executed / algorithmic FLOP of the convolution launches per training iteration (the profiled cycle is one
+        # pass over PATTERN): what rocprofv3's per-iteration kernel time of the same launches is priced against
+        cycle = max(len(PATTERN), 1)
+        exec_gflop_it, algo_gflop_it = mfma / 1e9 / cycle, flops / 1e9 / cycle
+        rocprof = None
         import glob
+        rp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_rocprof.json")))
+        if rp and prof and args.workload == "face128_n8" and not args.only and not args.deterministic:
+            with open(rp[-1]) as f:
+                conv_ms = json.load(f)["conv_ms_per_iteration"]
+            rocprof = {"achieved": exec_gflop_it / conv_ms["total"], "frac": exec_gflop_it / conv_ms["total"] / F32_MFMA_PEAK_TFLOPS,
+                       "conv_ms_per_iteration": conv_ms, "source": os.path.relpath(rp[-1], ROOT),
+                       "is": "this run's executed FLOP per iteration / the convolution kernels' time per iteration by rocprofv3 "
+                             "--kernel-trace inside the graph-replayed timed region of the SAME command, read from the committed "
+                             "profiles file (tools/profile_round.sh) — not measured inside this run; the HIP-event figure above "
+                             "carries ~5 us of event-pair cost per launch"}
+        traffic, traffic_src = None, None
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_modconv_pmc.json")))
         if pmc:  # HBM bytes per launch from separate rocprofv3 --pmc passes of this command
             with open(pmc[-1]) as f:
@@ -569,6 +647,8 @@ def main():
                                     "is": "direct-convolution FLOP of the same launches / the same time (Winograd "
                                           "launches alone exceed 1.0 on this scale: not a roofline, a speed-up)"},
                     "mfma_executed": {"achieved": executed, "frac": executed / F32_MFMA_PEAK_TFLOPS},   # = achieved / frac (kept: round-2 name)
+                    "executed_gflop_per_iteration": exec_gflop_it, "algorithmic_gflop_per_iteration": algo_gflop_it,
+                    "rocprof": rocprof,
                     # the same with the cost of an EMPTY event pair (measured in this run) taken off every
                     # launch: still conservative — rocprofv3's own durations (profiles/) are shorter again
                     "event_pair_overhead_us": pair_us,
@@ -601,13 +681,19 @@ def main():
                        else f"{args.workload.rsplit('_', 1)[0]}_n{args.n_proj}",
                        "image_size": cfg['image_size'], "gan_size": cfg['gan_size'], "n_proj_samples": args.n_proj,
                        "mfma_operands": cfg['mfma_operands'], "prior": cfg['prior_name'],
-                       "step_mix": "7:7:6 (step1:step2:step3, main.py:148 stage 0)" if not args.only
-                       else f"step{args.only} only (analysis run, not the BASELINE metric)",
-                       "images_per_rank": 1, "sharding": "one image per rank, no collective",
+                       "step_mix": (f"step{args.only} only (analysis run, not the BASELINE metric)" if args.only else
+                                    "13:22:18 (step1:step2:step3, main.py:141 joint training)" if joint else
+                                    "7:7:6 (step1:step2:step3, main.py:148 stage 0)"),
+                       "images_per_rank": 1,
+                       "sharding": ("joint training: one image per rank and iteration, one shared model, ONE all-reduce (mean) of "
+                                    "the optimiser's flat gradient bucket per step (17 / 55 / 90 MB), depth centre of step 1 over "
+                                    "all ranks" if joint else "one image per rank, no collective"),
                        **({"deterministic": "g2s_set_deterministic(1): bit-reproducible iterations (analysis run, "
                                             "not the BASELINE metric)"} if args.deterministic else {})},
             "ms_per_step_kind": {f"step{k}": v for k, v in kind_ms.items()},
-            "launch_mode": "eager" if args.eager else "hipGraph replay (one graph per step kind)",
+            "launch_mode": "eager" if args.eager else (
+                "hipGraph replay: two segments per step kind (forward + backward + bucket pack | optimiser step) with the "
+                "gradient all-reduce between them" if joint else "hipGraph replay (one graph per step kind)"),
             "final_loss": final_loss,
             "roofline": roofline,
             "roofline_other": roofline_other(device) if world == 1 and args.workload == "face128_n8"

@@ -57,6 +57,9 @@ struct ConvDesc {
     int groups, Cx, My;
     int cls_splitk[4];   // split-K slices of each class (<= splitk = grid.y): lighter classes get fewer
     const float *bias;   // [M] added after out_scale, or NULL
+    // StyledConv's NoiseInjection (stylegan2-pytorch/model.py:294-305,349-355) in the epilogue: + noise_w[0] *
+    // noise[oy * OWf + ox], one [OHf, OWf] map for all samples and channels; NULL: none
+    const float *noise, *noise_w;
     int act;             // 0: none, 1: leaky-ReLU(alpha) * gain applied after the bias
     float act_alpha, act_gain;
     ConvClass cls[4];
@@ -299,6 +302,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
         float *yb = d.y + (((size_t)b * d.My + grp * d.M) * d.OHf + oy) * d.OWf + ox;
         const float *ob = d.out_scale ? d.out_scale + (size_t)b * d.M : nullptr;
         const float *gbias = d.bias ? d.bias + grp * d.M : nullptr;
+        const float nz = d.noise ? d.noise_w[0] * d.noise[oy * d.OWf + ox] : 0.0f;
 #pragma unroll
         for (int i = 0; i < WMT; i++)
 #pragma unroll
@@ -308,6 +312,7 @@ __device__ __forceinline__ void modconv_body(const ConvDesc &d, const ConvClass 
                 float v = acc[i][j][r];
                 if (ob) v *= ob[m];
                 if (gbias) v += gbias[m];
+                v += nz;
                 if (d.act) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
                 float *dst = yb + (size_t)m * d.OHf * d.OWf;
                 if (atomic) unsafeAtomicAdd(dst, v);
@@ -1061,6 +1066,10 @@ struct WgradRider {
     bool dw_is_zero;
 };
 
+// Noise term of the epilogue for the NEXT launch of this thread (set and cleared by g2s_modconv_nba around its call:
+// an implementation detail of this file, no state survives an entry point).
+static thread_local const float *t_noise = nullptr, *t_noise_w = nullptr;
+
 static int conv_launch(const float *x, const float *w, const float *in_scale, const float *out_scale,
                        const float *bias, int act, float act_alpha, float act_gain, float *y, int B,
                        int Cr, int M, int H, int W, const ConvGeom &g, int tuned_tile, int tuned_splitk,
@@ -1078,6 +1087,9 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
     d.in_scale = in_scale;
     d.out_scale = out_scale;
     d.bias = bias;
+    d.noise = t_noise;
+    d.noise_w = t_noise_w;
+    G2S_REQUIRE(!d.noise || (!f16_operands && groups == 1), "the noise epilogue exists for the fp32 kernel only");
     d.act = act;
     d.act_alpha = act_alpha;
     d.act_gain = act_gain;
@@ -1182,9 +1194,11 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
     // A bias / activation epilogue needs the complete sum: with split-K it runs as a second,
     // elementwise launch (g2s_fused_bias_act in place) after the partial sums have been added.
     const bool split = splitk > 1;
-    const bool deferred_epilogue = split && (bias != nullptr || act != 0);
+    const bool deferred_epilogue = split && (bias != nullptr || act != 0 || d.noise != nullptr);
+    const float *noise = d.noise, *noise_w = d.noise_w;
     if (deferred_epilogue) {
         d.bias = nullptr;
+        d.noise = d.noise_w = nullptr;
         d.act = 0;
     }
     d.splitk = splitk;
@@ -1251,6 +1265,10 @@ static int conv_launch(const float *x, const float *w, const float *in_scale, co
     }
     int rc = check_launch("g2s_modconv");
     if (rc != G2S_OK || !deferred_epilogue) return rc;
+    if (noise) {    // StyledConv tail in place (bias is required there, act = leaky-ReLU)
+        G2S_REQUIRE(bias && act == 1, "noise epilogue: needs a bias and act = 1");
+        return g2s_noise_bias_act(y, noise, noise_w, bias, y, B, d.My, d.OHf * d.OWf, act_alpha, act_gain, stream);
+    }
     return g2s_fused_bias_act(y, bias, nullptr, y, (int64_t)B * d.My * d.OHf * d.OWf,
                               (int64_t)d.OHf * d.OWf, d.My, act ? 3 : 1, 0, act_alpha,
                               act ? act_gain : 1.0f, G2S_F32, stream);
@@ -1308,6 +1326,21 @@ extern "C" int g2s_modconv_ex(const float *x, const float *w, const float *in_sc
     G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
     return modconv_launch(x, w, in_scale, out_scale, bias, act, alpha, gain, y, B, Cin, Cout, H, W, k, mode,
                           transpose, stream, false, y_is_zero != 0);
+}
+
+// g2s_modconv_ex with the whole StyledConv tail (stylegan2-pytorch/model.py:349-355) in the epilogue:
+// y = gain * leaky_relu(out_scale * conv(in_scale * x) + noise_w[0] * noise[h, w] + bias[c], alpha).
+extern "C" int g2s_modconv_nba(const float *x, const float *w, const float *in_scale, const float *out_scale,
+                               const float *bias, const float *noise, const float *noise_w, float *y, int B, int Cin,
+                               int Cout, int H, int W, int k, int mode, int transpose, float alpha, float gain,
+                               int y_is_zero, g2s_stream_t stream) {
+    G2S_REQUIRE(bias && noise && noise_w, "bias, noise and noise_w must not be NULL");
+    t_noise = noise;
+    t_noise_w = noise_w;
+    const int rc = modconv_launch(x, w, in_scale, out_scale, bias, 1, alpha, gain, y, B, Cin, Cout, H, W, k, mode,
+                                  transpose, stream, false, y_is_zero != 0);
+    t_noise = t_noise_w = nullptr;
+    return rc;
 }
 
 // 1 if that launch adds into a cleared output (split-K slices / polyphase holes), else 0; < 0: error.

@@ -30,6 +30,7 @@ class GraphedSteps:
         self.graphs = {}
         self.loss = {}
         self.collected = {1: None, 2: None, 3: None}
+        self._static_src = {}
         self.warmup = warmup
         for opt in (trainer.optim_step1, trainer.optim_step2, trainer.optim_step3):
             for group in opt.param_groups:
@@ -79,11 +80,8 @@ class GraphedSteps:
                 optim.zero_grad(set_to_none=True)
                 warm_loss, warm_collected = self._iteration(kind, src)
         torch.cuda.current_stream().wait_stream(s)
-        g = torch.cuda.CUDAGraph()
         optim.zero_grad(set_to_none=True)
-        with torch.cuda.graph(g):
-            loss, collected = self._iteration(kind, src)
-        self.graphs[kind] = g
+        self.graphs[kind], loss, collected = self._record(kind, src)
         self.loss[kind] = loss.detach()
         self.collected[kind] = collected
         # A capture records, it does not run: the graph's static outputs (the loss, the hand-off
@@ -97,6 +95,13 @@ class GraphedSteps:
                     dst.copy_(srct.detach())
         return warmup  # iterations actually executed
 
+    def _record(self, kind, src):
+        """Capture one iteration -> (what run() replays, loss, collected)."""
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss, collected = self._iteration(kind, src)
+        return g, loss, collected
+
     def run(self, kind):
         """One training iteration of kind `kind` (graph replay)."""
         self.graphs[kind].replay()
@@ -105,3 +110,74 @@ class GraphedSteps:
     def set_sample(self, image, latent):
         self.image.copy_(image)
         self.latent.copy_(latent)
+
+
+class GraphedJointSteps(GraphedSteps):
+    """Joint (data-parallel) training iterations as TWO captured segments with the collective between them:
+
+        segment A   forward_stepK + backward + GradBucket.pack      (the step's gradients -> the flat bucket)
+        eager       ONE all-reduce (mean) of the bucket over RCCL   (skipped by a single process)
+        segment B   optimiser step reading the bucket's views       (GradBucket.bind: nothing is copied back)
+
+    Every address is fixed (the bucket is persistent, the gradients of segment A live in the graph's pool), so
+    a replayed iteration is  A.replay(); all_reduce(bucket); B.replay().  The forward itself must hold no
+    collective: steps 2 / 3 always qualify (one image at a time, centred by its own mean at any W —
+    GeneralizingTrainer2); step 1 qualifies when the depth centre is local (`model.batch_mean is None`: a
+    single process, or one image per rank WITHOUT the whole-batch centre) and is refused otherwise — the
+    trainer then runs it eagerly (sharding.global_mean is a differentiable all-reduce inside the forward)."""
+
+    def __init__(self, trainer, image, latent, warmup=3):
+        super().__init__(trainer, image, latent, warmup)
+        from .sharding import bucket_of
+        self.buckets = {k: bucket_of([p for g in getattr(trainer, f'optim_step{k}').param_groups for p in g['params']])
+                        for k in (1, 2, 3)}
+
+    def _forward_backward(self, kind, src):
+        loss, collected = getattr(self.model, f'forward_step{kind}')(
+            self.image, self.latent, src, n_proj_samples=self.t.n_proj_samples)
+        loss.backward()
+        self.buckets[kind].pack()
+        return loss, collected
+
+    def _update(self, kind):
+        self.buckets[kind].bind()
+        getattr(self.t, f'optim_step{kind}').step()
+        zeropool.end()
+
+    def _iteration(self, kind, src):
+        if kind == 1 and self.model.batch_mean is not None:
+            raise RuntimeError("GraphedJointSteps: step 1 with a whole-batch depth centre holds a collective in its forward; run it eagerly")
+        loss, collected = self._forward_backward(kind, src)
+        self.buckets[kind].all_reduce_mean()
+        self._update(kind)
+        return loss, collected
+
+    def _record(self, kind, src):
+        if kind == 1 and self.model.batch_mean is not None:
+            raise RuntimeError("GraphedJointSteps: step 1 with a whole-batch depth centre holds a collective in its forward; run it eagerly")
+        a, b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(a):
+            loss, collected = self._forward_backward(kind, src)
+        with torch.cuda.graph(b, pool=a.pool()):
+            self._update(kind)
+        return (a, b), loss, collected
+
+    def run(self, kind):
+        a, b = self.graphs[kind]
+        a.replay()
+        self.buckets[kind].all_reduce_mean()
+        b.replay()
+        return self.loss[kind]
+
+    def set_source(self, kind, collected):
+        """Copy a hand-off into the static tensors the captured graph of step `kind` reads (the joint trainer
+        hands every image its own slice of the batched step 1)."""
+        cur = self._static_src.get(kind)
+        if cur is None:
+            self._static_src[kind] = cur = tuple(t.detach().clone() if torch.is_tensor(t) else t for t in collected)
+            self.collected[kind - 1] = cur
+            return
+        with torch.no_grad():
+            for dst, srct in zip(cur, collected):
+                if torch.is_tensor(dst):
+                    dst.copy_(srct)

@@ -211,12 +211,18 @@ class GeneralizingTrainer2(Trainer):
 
     def fit(self, images_latents, plot_depth_map=False,
             stages=[{'step1': 1, 'step2': 1, 'step3': 1}] * 2, batch_size=2, shuffle=False,
-            rank=0, world_size=1, **_):
+            rank=0, world_size=1, graphs=False, **_):
+        """graphs=True: the per-image steps 2 / 3 replay as HIP graphs in two segments with the gradient
+        all-reduce between them (graphs.GraphedJointSteps; needs capturable=True and a non-default current
+        stream); the batched step 1 stays eager (ragged batches, and under W > 1 a collective in its forward)."""
         from . import sharding
         # centre of the depth over the WHOLE image batch (all ranks) — only where the reference
         # itself runs a batch of images through the depth net: prior pre-training and step 1
         whole_batch = sharding.global_mean if world_size > 1 else None
         total_it = 0
+        graphed = None
+        if graphs and not self.capturable:
+            raise RuntimeError("graphs=True needs GeneralizingTrainer2(..., capturable=True)")
         try:
             if self.load_dict is None:
                 self.model.batch_mean = whole_batch
@@ -245,6 +251,27 @@ class GeneralizingTrainer2(Trainer):
                                            lights_b[bi:bi + 1].detach(), albedos[bi:bi + 1].detach(),
                                            depths[bi:bi + 1].detach(), canon_masks[bi])
                         loss2 = loss3 = step2_collected = None
+                        if graphs:
+                            from .graphs import GraphedJointSteps
+                            if graphed is None:
+                                graphed = GraphedJointSteps(self, image, latent)
+                            else:
+                                graphed.set_sample(image, latent)
+                            graphed.set_source(2, step1_collected)
+                            n2, n3 = stages[0]['step2'], stages[0]['step3']
+                            n3 = n3 if n2 > 0 else 0        # no step-2 hand-off, no step 3 (as in the eager loop below)
+                            for step, n in ((2, n2), (3, n3)):
+                                done = 0
+                                if n > 0 and step not in graphed.graphs:     # warm-up iterations are real iterations
+                                    done = graphed.capture(step, warmup=min(graphed.warmup, n))
+                                for _ in range(n - done):
+                                    graphed.run(step)
+                                total_it += n
+                            loss2 = graphed.loss.get(2) if n2 > 0 else None
+                            loss3 = graphed.loss.get(3) if n3 > 0 else None
+                            self.history.append((index, epoch, 2, None if loss2 is None else float(loss2)))
+                            self.history.append((index, epoch, 3, None if loss3 is None else float(loss3)))
+                            continue
                         for _ in range(stages[0]['step2']):
                             self.optim_step2.zero_grad()
                             loss2, step2_collected = self.model.forward_step2(

@@ -79,6 +79,27 @@ def test_single_process_is_a_noop():
     assert sharding.global_mean(torch.tensor([1.0, 3.0])) == 2.0
 
 
+def test_grad_bucket_pack_bind_and_inplace_accumulation():
+    """sharding.GradBucket: gradients travel into ONE persistent flat buffer (a missing gradient as zeros), the
+    parameters' .grad become views of it (nothing copied back), a gradient accumulated in place into a bound view
+    is not copied again, and the same parameter list always gets the same bucket."""
+    ps = [torch.nn.Parameter(torch.zeros(3, 2)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(4))]
+    b = sharding.bucket_of(ps)
+    assert sharding.bucket_of(ps) is b and b.flat.numel() == 15
+    ps[0].grad, ps[2].grad = torch.arange(6.0).view(3, 2), torch.full((4,), 7.0)
+    b.flat.fill_(-1.0)
+    b.pack()
+    assert torch.equal(b.flat, torch.cat([torch.arange(6.0), torch.zeros(5), torch.full((4,), 7.0)]))
+    b.bind()
+    assert all(p.grad.data_ptr() == v.data_ptr() and p.grad.shape == p.shape for p, v in zip(ps, b.views))
+    ps[1].grad.add_(2.0)                       # autograd accumulates in place into a bound view
+    b.pack()                                   # nothing to move
+    assert torch.equal(b.flat[6:11], torch.full((5,), 2.0))
+    ps[1].grad = None                          # zero_grad(set_to_none=True), then a step without this gradient
+    b.pack()
+    assert torch.equal(b.flat[6:11], torch.zeros(5)) and torch.equal(b.flat[:6], torch.arange(6.0))
+
+
 # ------------------------------------------------------------------ joint trainer (GeneralizingTrainer2)
 class _ToyModel(torch.nn.Module):
     """CPU stand-in with the model step API the trainers drive (trainer.py:40-48,103-104,147): the

@@ -191,3 +191,85 @@ def test_every_step_kind_lowers_its_own_loss(scenario):
         # (measured: step 2 falls with 3 - 5 small upticks in 30 iterations, step 3 monotonically) most updates lower it
         assert max(curve) <= 1.02 * curve[0], (step, curve)
         assert np.mean(np.diff(curve) < 0) >= 0.7, (step, curve)
+
+
+# ----------------------------------------------------------------------------- joint mode: flat bucket + graph segments
+def _joint_graph_worker(rank, world, port, q, graphs):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+    from gan2shape_amd import sharding
+    from gan2shape_amd.model import GAN2Shape
+    from gan2shape_amd.trainer import GeneralizingTrainer2
+    if world > 1:
+        sharding.init_distributed("gloo")      # both ranks share the one GPU of the test box
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    cfg = bench.face_config(n_proj=2)
+    cfg.update(n_epochs_prior=1, n_epochs_generalized=1)
+    torch.manual_seed(0)
+    t = GeneralizingTrainer2(GAN2Shape, cfg, device=dev, capturable=True)
+    data = []
+    for i in range(2 * world):
+        image, latent = bench.synthetic_sample(t.model, 100 + i, dev)
+        data.append((image[0].cpu(), latent[0].cpu(), i))
+    stages = [{'step1': 1, 'step2': 5, 'step3': 4}]
+    n = t.fit(data, stages=stages, batch_size=world, rank=rank, world_size=world, graphs=graphs)
+    nets = ('depth_net', 'albedo_net', 'viewpoint_net', 'lighting_net', 'offset_encoder_net')
+    flat = torch.cat([p.detach().reshape(-1).cpu() for nme, p in t.model.named_parameters() if nme.split('.')[0] in nets])
+    # the optimisers' persistent flat buckets exist (one per optimiser that packed): 17 / 55 / 90 MB
+    bound = (len(sharding._BUCKETS) >= (3 if world > 1 else 2)) if (world > 1 or graphs) else True
+    q.put((rank, n, float(flat.double().sum()), float(flat.double().abs().sum()), bool(torch.isfinite(flat).all()),
+           [h[3] for h in t.history], bound))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def _spawn_joint(world, graphs):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_joint_graph_worker, args=(r, world, port, q, graphs)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=400) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_joint_trainer_graph_segments_one_rank():
+    """GeneralizingTrainer2.fit(graphs=True): steps 2 / 3 of every image replay as two captured segments
+    (forward + backward + GradBucket.pack | optimiser step from the bucket's views); same iteration count and
+    history shape as the eager loop, finite losses, and losses of the same size (the random draws of a
+    replayed graph come from the graph-registered generator, so the two runs are not bit-equal)."""
+    (_, n_e, s_e, a_e, ok_e, hist_e, _), = _spawn_joint(1, False)
+    (_, n_g, s_g, a_g, ok_g, hist_g, bound), = _spawn_joint(1, True)
+    assert ok_e and ok_g and bound
+    assert n_e == n_g == 2 * (1 + 5 + 4)
+    assert len(hist_e) == len(hist_g) and all(np.isfinite(v) for v in hist_g)
+    # step 1 draws nothing at random: its loss on the first batch is the same run (summation-order noise only)
+    assert abs(hist_e[0] - hist_g[0]) <= 1e-4 * abs(hist_e[0]), (hist_e[0], hist_g[0])
+    for a, b in zip(hist_e, hist_g):
+        assert 0.5 < a / b < 2.0, (hist_e, hist_g)
+    assert abs(a_e - a_g) <= 1e-2 * a_e
+
+
+def test_joint_trainer_graph_segments_two_ranks_share_parameters():
+    """The same with world_size 2 (gloo between two processes on the one GPU): each rank replays segment A on
+    ITS image, the flat bucket is all-reduced between the segments, segment B steps from the averaged
+    bucket — both ranks must end on the same parameters (they would drift apart within one iteration if
+    the collective missed a replay, since the ranks train different images)."""
+    res = _spawn_joint(2, True)
+    (_, n0, s0, a0, ok0, h0, b0), (_, n1, s1, a1, ok1, h1, b1) = res
+    assert ok0 and ok1 and b0 and b1 and n0 == n1 == 2 * (1 + 5 + 4)
+    assert abs(s0 - s1) <= 1e-6 * a0 and abs(a0 - a1) <= 1e-6 * a0
+    assert h0 != h1          # different images: different losses, same parameters

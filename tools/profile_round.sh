@@ -13,7 +13,7 @@ python3 $R/bench.py --steps 20 --warmup 10 --no-cpu-baseline > $O/warm.json 2> $
 echo "[2] kernel trace + stats of the default bench command"
 G2S_BENCH_MARK=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 cp $(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
-python3 $R/tools/window_trace.py $(find /tmp/prof_bench -name "*kernel_trace.csv" | head -1) 40 40 > $O/bench_timed_region.txt
+python3 $R/tools/window_trace.py $(find /tmp/prof_bench -name "*kernel_trace.csv" | head -1) 40 40 $O/conv_rocprof.json > $O/bench_timed_region.txt
 echo "[3] PMC FETCH_SIZE"
 timeout -k 5 400 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_f -o f --output-format csv -- python3 $R/tools/pmc_iter.py > $O/pmc_fetch.log 2>&1
 echo "[4] PMC WRITE_SIZE"

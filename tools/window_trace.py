@@ -1,8 +1,12 @@
 """Summarise the timed region of a `G2S_BENCH_MARK=1 python bench.py ...` rocprofv3 kernel trace:
 keeps the launches between the two marker kernels (bitwise_not), prints category totals per
-iteration and the top kernels.  python tools/window_trace.py <kernel_trace.csv> <iters> [top]"""
+iteration and the top kernels.  python tools/window_trace.py <kernel_trace.csv> <iters> [top] [summary.json]
+The optional JSON holds the per-iteration time of the fp32-MFMA convolution kernels in the timed region:
+bench.py reads the newest committed profiles/r*_conv_rocprof.json and prices the run's executed FLOP against
+it (roofline.rocprof) beside its own HIP-event figure."""
 import collections
 import csv
+import json
 import sys
 
 trace, iters = sys.argv[1], float(sys.argv[2])
@@ -45,3 +49,13 @@ for c, v in tot.most_common():
 print("top kernels (per iteration):")
 for n, v in sorted(per.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"  {v[1] / iters / 1e3:7.3f} ms {100 * v[1] / T:5.1f}% n={v[0] / iters:6.1f} avg={v[1] / v[0]:8.1f}us  {n[:120]}")
+if len(sys.argv) > 4:
+    direct, wino = tot["g2s modconv (MFMA implicit GEMM)"], tot["g2s winograd (MFMA F(2x2,3x3))"]
+    with open(sys.argv[4], "w") as f:
+        json.dump({"what": "rocprofv3 --kernel-trace durations inside the graph-replayed timed region of bench.py (G2S_BENCH_MARK=1), per iteration",
+                   "iterations": iters, "launches_per_iteration": len(rows) / iters, "kernel_ms_per_iteration": T / iters / 1e3,
+                   "wall_ms_per_iteration": span / iters,
+                   "conv_ms_per_iteration": {"direct": direct / iters / 1e3, "winograd": wino / iters / 1e3,
+                                             "total": (direct + wino) / iters / 1e3},
+                   "conv_launches_per_iteration": {"direct": cnt["g2s modconv (MFMA implicit GEMM)"] / iters,
+                                                   "winograd": cnt["g2s winograd (MFMA F(2x2,3x3))"] / iters}}, f, indent=1)
