@@ -1305,13 +1305,14 @@ static int modconv_launch(const float *x, const float *w, const float *in_scale,
     if (!g.adjoint && mode != G2S_CONV_PLAIN) G2S_REQUIRE(H >= k && W >= k, "input smaller than the kernel");
     int tile = -1, splitk = -1;
     if (H == W && !f16_operands)
-        for (const TunedConv *t = kTuned; t->B; ++t)
-            if (t->B == B && t->Cin == Cin && t->Cout == Cout && t->H == H && t->k == k && t->mode == mode &&
-                t->transpose == transpose && t->fused == (bias != nullptr || act != 0)) {
-                tile = t->tile;
-                splitk = t->splitk;
-                break;
-            }
+        for (int pass = 0; pass < 2 && tile == -1 && splitk == -1; pass++)   // pass 1: the row measured without / with the epilogue
+            for (const TunedConv *t = kTuned; t->B; ++t)
+                if (t->B == B && t->Cin == Cin && t->Cout == Cout && t->H == H && t->k == k && t->mode == mode &&
+                    t->transpose == transpose && (pass == 1 || t->fused == (bias != nullptr || act != 0))) {
+                    tile = t->tile;
+                    splitk = t->splitk;
+                    break;
+                }
     return conv_launch(x, w, in_scale, out_scale, bias, act, act_alpha, act_gain, y, B,
                        transpose ? Cout : Cin, transpose ? Cin : Cout, H, W, g, tile, splitk, stream, y_is_zero,
                        f16_operands, 1, nullptr, plan_needs_zero);

@@ -105,9 +105,89 @@ __global__ __launch_bounds__(256) void demod_bwd(const float *__restrict__ wsq,
     }
 }
 
+// One pass over the activation x = gain * leaky_relu(yconv + noise_w * noise + bias) that sits between two layers of
+// the frozen generator, in the BACKWARD pass (synthesis.py): x is the output of the producer layer's StyledConv tail
+// and the input of its consumers — the next modulated convolution (g1 = gradient w.r.t. s1 * x from its data-gradient
+// GEMM) and, behind every second layer, ToRGB (g2, s2).  Per row r = (b, c), n = H * W:
+//     dot1[r] = sum_i x * g1          dot2[r] = sum_i x * g2          (the consumers' style gradients)
+//     out[r,i] = (g1 * s1[r] + g2 * s2[r]) * gain * (x > 0 ? 1 : slope)   (gradient w.r.t. the producer's
+//                                                                          pre-activation: FusedLeakyReLU's gate)
+//     gdot[r] = sum_i out * yconv / demod[r],  yconv = (x > 0 ? x : x / slope) / gain - noise_w * noise[i] - bias[c]
+//               (d loss / d demod of the producer; its convolution output is recovered from x: the leaky ReLU is
+//               invertible, so the forward never stores the pre-activation)
+// replacing four passes (rows_dot_scale x 2, the accumulation of the two consumers' gradients, the gate) by one.
+// One wavefront per row; every operand is read once.
+__global__ __launch_bounds__(256) void synth_rows(const float *__restrict__ x, const float *__restrict__ g1,
+                                                  const float *__restrict__ s1, const float *__restrict__ g2,
+                                                  const float *__restrict__ s2, const float *__restrict__ noise,
+                                                  const float *__restrict__ noise_w, const float *__restrict__ bias,
+                                                  const float *__restrict__ demod, float *__restrict__ out,
+                                                  float *__restrict__ dot1, float *__restrict__ dot2,
+                                                  float *__restrict__ gdot, int rows, int channels, int n, float slope,
+                                                  float gain, int vec) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const size_t off = (size_t)row * n;
+    const float *xr = x + off, *g1r = g1 + off, *g2r = g2 ? g2 + off : nullptr;
+    float *orow = out ? out + off : nullptr;
+    const float a1 = s1[row], a2 = g2 ? s2[row] : 0.0f;
+    const float nw = gdot ? noise_w[0] : 0.0f, bi = gdot ? bias[row % channels] : 0.0f;
+    const float inv_gain = 1.0f / gain, inv_slope = 1.0f / slope;
+    float d1 = 0.0f, d2 = 0.0f, dg = 0.0f;
+    auto one = [&](float xv, float gv1, float gv2, float nz) {
+        d1 += xv * gv1;
+        d2 += xv * gv2;
+        const float o = (gv1 * a1 + gv2 * a2) * (xv > 0.0f ? gain : gain * slope);
+        if (gdot) dg += o * ((xv > 0.0f ? xv : xv * inv_slope) * inv_gain - nw * nz - bi);
+        return o;
+    };
+    if (vec) {
+        for (int i = lane; i < (n >> 2); i += 64) {
+            const float4 xv = reinterpret_cast<const float4 *>(xr)[i];
+            const float4 v1 = reinterpret_cast<const float4 *>(g1r)[i];
+            const float4 v2 = g2r ? reinterpret_cast<const float4 *>(g2r)[i] : float4{0.f, 0.f, 0.f, 0.f};
+            const float4 nz = gdot ? reinterpret_cast<const float4 *>(noise)[i] : float4{0.f, 0.f, 0.f, 0.f};
+            float4 o;
+            o.x = one(xv.x, v1.x, v2.x, nz.x);
+            o.y = one(xv.y, v1.y, v2.y, nz.y);
+            o.z = one(xv.z, v1.z, v2.z, nz.z);
+            o.w = one(xv.w, v1.w, v2.w, nz.w);
+            if (orow) reinterpret_cast<float4 *>(orow)[i] = o;
+        }
+    } else {
+        for (int i = lane; i < n; i += 64) {
+            const float o = one(xr[i], g1r[i], g2r ? g2r[i] : 0.0f, gdot ? noise[i] : 0.0f);
+            if (orow) orow[i] = o;
+        }
+    }
+    d1 = wave_sum(d1);
+    d2 = wave_sum(d2);
+    dg = wave_sum(dg);
+    if (lane == 0) {
+        dot1[row] = d1;
+        if (dot2) dot2[row] = d2;
+        if (gdot) gdot[row] = dg / demod[row];
+    }
+}
+
 }  // namespace g2s
 
 using namespace g2s;
+
+extern "C" int g2s_synth_bwd_rows(const float *x, const float *g1, const float *s1, const float *g2, const float *s2,
+                                  const float *noise, const float *noise_w, const float *bias, const float *demod,
+                                  float *out, float *dot1, float *dot2, float *gdot, int rows, int channels, int n,
+                                  float slope, float gain, g2s_stream_t stream) {
+    G2S_REQUIRE(x && g1 && s1 && dot1 && rows > 0 && channels > 0 && n > 0, "x, g1, s1, dot1 must not be NULL; sizes positive");
+    G2S_REQUIRE((g2 == nullptr) == (s2 == nullptr) && (g2 == nullptr) == (dot2 == nullptr), "g2, s2, dot2 come together");
+    G2S_REQUIRE(!gdot || (noise && noise_w && bias && demod), "gdot needs noise, noise_w, bias, demod");
+    G2S_REQUIRE(slope > 0.0f && gain > 0.0f, "slope and gain must be positive (the activation is inverted)");
+    uintptr_t bits = (uintptr_t)x | (uintptr_t)g1 | (uintptr_t)g2 | (uintptr_t)out | (gdot ? (uintptr_t)noise : 0);
+    const int vec = (n % 4 == 0) && (bits & 15) == 0;
+    synth_rows<<<cdiv(rows, 4), 256, 0, as_stream(stream)>>>(x, g1, s1, g2, s2, noise, noise_w, bias, demod, out, dot1,
+                                                               dot2, gdot, rows, channels, n, slope, gain, vec);
+    return check_launch("g2s_synth_bwd_rows");
+}
 
 extern "C" int g2s_rows_dot_scale(const float *a, const float *b, const float *s, const float *inv,
                                   float *out, float *dot, int rows, int n, g2s_stream_t stream) {

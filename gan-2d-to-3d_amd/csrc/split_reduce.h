@@ -17,7 +17,9 @@ constexpr int SPLIT_REDUCE_MAX = 8;   // most slices one pass adds (all copies a
 
 // y[i] = act(sum_{s < slices} part[s * n + i] + bias[channel(i)]),  channel(i) = (i / hw) % channels;
 // bias may be NULL; act 0: none, 1: leaky-ReLU(alpha) * gain.
+// noise / noise_w (optional): + noise_w[0] * noise[i % hw] with the bias (StyledConv's NoiseInjection).
 int split_reduce_launch(const float *part, int slices, int64_t n, float *y, const float *bias, int64_t hw,
-                        int channels, int act, float alpha, float gain, g2s_stream_t stream);
+                        int channels, int act, float alpha, float gain, g2s_stream_t stream,
+                        const float *noise = nullptr, const float *noise_w = nullptr);
 
 }  // namespace g2s

@@ -16,7 +16,20 @@ namespace g2s {
 struct UpfirParams {
     int major, in_h, in_w, out_h, out_w, kh, kw;
     int up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+    // optional epilogue (g2s_upfirdn2d_nba): the StyledConv tail behind the blur of an up-sampling layer —
+    // gain * leaky_relu(out + noise_w[0] * noise[oy, ox] + bias[m % channels], alpha); bias == NULL: none
+    const float *bias, *noise, *noise_w;
+    int channels;
+    float alpha, gain;
 };
+
+template <typename T> __device__ __forceinline__ float upfir_finish(const UpfirParams &p, float acc, int m, int oy, int ox) {
+    if (p.bias) {
+        acc += p.bias[m % p.channels] + p.noise_w[0] * p.noise[oy * p.out_w + ox];
+        acc = (acc > 0.0f ? acc : acc * p.alpha) * p.gain;
+    }
+    return acc;
+}
 
 __device__ __host__ __forceinline__ int floor_div(int a, int b) {
     int q = a / b;
@@ -112,7 +125,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T *__restrict__ x,
                     for (int ky = 0; ky < KH; ky++)
 #pragma unroll
                         for (int kx = 0; kx < KW; kx++) acc += win[r * DOWN + ky][kx] * kr[ky][kx];
-                    if (oy0 + r < p.out_h) stf<T>(y + ((size_t)m * p.out_h + oy0 + r) * p.out_w + ox, acc);
+                    if (oy0 + r < p.out_h)
+                        stf<T>(y + ((size_t)m * p.out_h + oy0 + r) * p.out_w + ox, upfir_finish<T>(p, acc, m, oy0 + r, ox));
                 }
             }
             }
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tiled(const T *__restrict__ x,
                     const int ky = ky0 + j * UP, kx = kx0 + i * UP;
                     if (ky < KH && kx < KW) acc += sx[ry0 + j][rx0 + i] * sk[ky][kx];
                 }
-            stf<T>(y + ((size_t)m * p.out_h + oy) * p.out_w + ox, acc);
+            stf<T>(y + ((size_t)m * p.out_h + oy) * p.out_w + ox, upfir_finish<T>(p, acc, m, oy, ox));
         }
         }
         }
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(const T *__restrict__ x
                        k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
             }
         }
-        stf<T>(y + i, acc);
+        stf<T>(y + i, upfir_finish<T>(p, acc, m, oy, ox));
     }
 }
 
@@ -213,14 +227,21 @@ static int dispatch(const T *x, const float *k, T *y, const UpfirParams &p, hipS
 
 using namespace g2s;
 
-extern "C" int g2s_upfirdn2d(const void *x, const float *k, void *y, int major, int in_h, int in_w,
-                             int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
-                             int pad_x1, int pad_y0, int pad_y1, int dtype, g2s_stream_t stream) {
+static int upfirdn2d_launch(const void *x, const float *k, void *y, int major, int in_h, int in_w,
+                            int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                            int pad_x1, int pad_y0, int pad_y1, int dtype, g2s_stream_t stream, int channels,
+                            const float *bias, const float *noise, const float *noise_w, float alpha, float gain) {
     G2S_REQUIRE(x && k && y, "x, k, y must not be NULL");
     G2S_REQUIRE(major > 0 && in_h > 0 && in_w > 0 && kh > 0 && kw > 0, "sizes must be positive");
     G2S_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, "up/down must be positive");
     G2S_REQUIRE(dtype == G2S_F32 || dtype == G2S_F16, "dtype must be G2S_F32 or G2S_F16");
-    UpfirParams p;
+    UpfirParams p{};
+    p.bias = bias;
+    p.noise = noise;
+    p.noise_w = noise_w;
+    p.channels = channels;
+    p.alpha = alpha;
+    p.gain = gain;
     p.major = major;
     p.in_h = in_h;
     p.in_w = in_w;
@@ -238,4 +259,24 @@ extern "C" int g2s_upfirdn2d(const void *x, const float *k, void *y, int major, 
     hipStream_t st = as_stream(stream);
     if (dtype == G2S_F32) return dispatch<float>((const float *)x, k, (float *)y, p, st);
     return dispatch<__half>((const __half *)x, k, (__half *)y, p, st);
+}
+
+extern "C" int g2s_upfirdn2d(const void *x, const float *k, void *y, int major, int in_h, int in_w,
+                             int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                             int pad_x1, int pad_y0, int pad_y1, int dtype, g2s_stream_t stream) {
+    return upfirdn2d_launch(x, k, y, major, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,
+                            pad_y1, dtype, stream, 1, nullptr, nullptr, nullptr, 0.0f, 1.0f);
+}
+
+// upfirdn2d (float32) with the StyledConv tail of an up-sampling layer in its store (stylegan2-pytorch/
+// model.py:264-275 Blur, then :349-355): y = gain * leaky_relu(upfirdn2d(x) + noise_w[0] * noise[oy, ox] +
+// bias[m % channels], alpha); x [major = B * channels, in_h, in_w], noise [out_h, out_w].
+extern "C" int g2s_upfirdn2d_nba(const float *x, const float *k, float *y, int major, int channels, int in_h, int in_w,
+                                 int kh, int kw, int up, int down, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                 const float *bias, const float *noise, const float *noise_w, float alpha, float gain,
+                                 g2s_stream_t stream) {
+    G2S_REQUIRE(bias && noise && noise_w && channels > 0 && major % channels == 0,
+                "bias, noise, noise_w must not be NULL; major must be a multiple of channels");
+    return upfirdn2d_launch(x, k, y, major, in_h, in_w, kh, kw, up, up, down, down, pad_x0, pad_x1, pad_y0, pad_y1,
+                            G2S_F32, stream, channels, bias, noise, noise_w, alpha, gain);
 }

@@ -66,6 +66,8 @@ struct WinoDesc {
     float act_alpha, act_gain;
     float *part;         // split-K with a workspace: slice s stores to part[s * part_n + offset in y]
     long part_n;
+    // NoiseInjection of StyledConv in the epilogue (with the bias): + noise_w[0] * noise[oy * W + ox]; NULL: none
+    const float *noise, *noise_w;
 };
 
 // PARTIAL: Cr is not a multiple of the K tile (the last tile's surplus channels read as zero).
@@ -356,6 +358,15 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
         const bool vec = col1 && (d.W & 1) == 0 && !split;
         float *yb = d.y + ((size_t)b * d.M * d.H + oy) * d.W + ox;
         const float *ob = d.out_scale ? d.out_scale + (size_t)b * d.M : nullptr;
+        float nz[4] = {0.f, 0.f, 0.f, 0.f};     // the noise term of this lane's 2x2 outputs (same for every channel)
+        if (d.noise && !(split && d.part != nullptr)) {
+            const float nw = d.noise_w[0];
+            const float *np_ = d.noise + oy * d.W + ox;
+            nz[0] = nw * np_[0];
+            if (col1) nz[1] = nw * np_[1];
+            if (row1) nz[2] = nw * np_[d.W];
+            if (row1 && col1) nz[3] = nw * np_[d.W + 1];
+        }
     #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int m = mt * WBM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(WTHREADS) void wino_kernel(WinoDesc d) {
             const float bi = (d.bias && !raw) ? d.bias[m] : 0.0f;
     #pragma unroll
             for (int q = 0; q < 4; q++) {
-                float v = y[q] * sc + bi;
+                float v = y[q] * sc + bi + nz[q];
                 if (d.act && !raw) v = (v > 0.0f ? v : v * d.act_alpha) * d.act_gain;
                 y[q] = v;
             }
@@ -439,6 +450,11 @@ __global__ __launch_bounds__(256) void wino_streamk_reduce_kernel(WinoDesc d) {
         const float bi = d.bias ? d.bias[m] : 0.0f;
         acc.x += bi;
         acc.y += bi;
+        if (d.noise) {
+            const float nw = d.noise_w[0];
+            acc.x += nw * d.noise[oy * d.W + 2 * px];
+            acc.y += nw * d.noise[oy * d.W + 2 * px + 1];
+        }
         if (d.act) {
             acc.x = (acc.x > 0.0f ? acc.x : acc.x * d.act_alpha) * d.act_gain;
             acc.y = (acc.y > 0.0f ? acc.y : acc.y * d.act_alpha) * d.act_gain;
@@ -501,10 +517,10 @@ extern "C" int g2s_wino_weights(const float *w, float *U, int Cout, int Cin, int
     return check_launch("g2s_wino_weights");
 }
 
-extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_scale, const float *out_scale,
-                                const float *bias, float *y, int B, int Cr, int M, int H, int W, int act,
-                                float alpha, float gain, int splitk, float *ws, int64_t ws_floats,
-                                g2s_stream_t stream) {
+static int wino_launch(const float *x, const float *U, const float *in_scale, const float *out_scale,
+                       const float *bias, const float *noise, const float *noise_w, float *y, int B, int Cr, int M,
+                       int H, int W, int act, float alpha, float gain, int splitk, float *ws, int64_t ws_floats,
+                       g2s_stream_t stream) {
     G2S_REQUIRE(x && U && y, "x, U, y must not be NULL");
     G2S_REQUIRE(B > 0 && Cr > 0 && M > 0 && H >= 2 && W >= 2, "sizes must be positive (H, W >= 2)");
     G2S_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-ReLU)");
@@ -517,6 +533,8 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
     d.in_scale = in_scale;
     d.out_scale = out_scale;
     d.bias = bias;
+    d.noise = noise;
+    d.noise_w = noise_w;
     d.y = y;
     d.B = B;
     d.Cr = Cr;
@@ -598,9 +616,10 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
         d.upw = 0;
         partial_sums = false;
     }
-    const bool deferred = partial_sums && !streamk_part && (bias != nullptr || act != 0);
+    const bool deferred = partial_sums && !streamk_part && (bias != nullptr || act != 0 || noise != nullptr);
     if (deferred) {
         d.bias = nullptr;
+        d.noise = d.noise_w = nullptr;
         d.act = 0;
     }
     d.splitk = splitk;
@@ -627,8 +646,30 @@ extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_
         return check_launch("g2s_conv3x3_wino (stream-K reduce)");
     }
     if (rc == G2S_OK && use_part)
-        return split_reduce_launch(ws, splitk, (int64_t)y_floats, y, bias, (int64_t)H * W, M, act, alpha, gain, stream);
+        return split_reduce_launch(ws, splitk, (int64_t)y_floats, y, bias, (int64_t)H * W, M, act, alpha, gain, stream,
+                                   noise, noise_w);
     if (rc != G2S_OK || !deferred) return rc;
+    if (noise)
+        return g2s_noise_bias_act(y, noise, noise_w, bias, y, B, M, H * W, alpha, gain, stream);
     return g2s_fused_bias_act(y, bias, nullptr, y, (int64_t)B * M * H * W, (int64_t)H * W, M, act ? 3 : 1, 0,
                               alpha, act ? gain : 1.0f, G2S_F32, stream);
+}
+
+extern "C" int g2s_conv3x3_wino(const float *x, const float *U, const float *in_scale, const float *out_scale,
+                                const float *bias, float *y, int B, int Cr, int M, int H, int W, int act,
+                                float alpha, float gain, int splitk, float *ws, int64_t ws_floats,
+                                g2s_stream_t stream) {
+    return wino_launch(x, U, in_scale, out_scale, bias, nullptr, nullptr, y, B, Cr, M, H, W, act, alpha, gain, splitk,
+                       ws, ws_floats, stream);
+}
+
+// The same with the whole StyledConv tail (stylegan2-pytorch/model.py:349-355) in the epilogue:
+// y = gain * leaky_relu(out_scale * conv(in_scale * x) + noise_w[0] * noise[h, w] + bias[m], alpha).
+extern "C" int g2s_conv3x3_wino_nba(const float *x, const float *U, const float *in_scale, const float *out_scale,
+                                    const float *bias, const float *noise, const float *noise_w, float *y, int B, int Cr,
+                                    int M, int H, int W, float alpha, float gain, int splitk, float *ws,
+                                    int64_t ws_floats, g2s_stream_t stream) {
+    G2S_REQUIRE(bias && noise && noise_w, "bias, noise and noise_w must not be NULL");
+    return wino_launch(x, U, in_scale, out_scale, bias, noise, noise_w, y, B, Cr, M, H, W, 1, alpha, gain, splitk, ws,
+                       ws_floats, stream);
 }

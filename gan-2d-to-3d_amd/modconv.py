@@ -101,6 +101,8 @@ def wino_choice(x, w, mode, transpose, fused):
         return None if WINO_FORCE == "direct" else int(WINO_FORCE)
     M = w.shape[1] if transpose else w.shape[0]
     hit = _WINO_TABLE.get((B, Cr, M, H, W, int(transpose), int(fused)))
+    if hit is None:     # the row measured without / with the epilogue
+        hit = _WINO_TABLE.get((B, Cr, M, H, W, int(transpose), 1 - int(fused)))
     if hit is not None:
         return None if hit == "direct" else int(hit)
     # unmeasured signature: Winograd when there is enough work for the 64-channel x 64-tile
@@ -144,6 +146,44 @@ def _wino_launch(x, w, in_scale, out_scale, bias, transpose, act, alpha, gain, y
         _lib.check(L.g2s_conv3x3_wino(_lib.ptr(x), _lib.ptr(U), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                       _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W, int(act), float(alpha),
                                       float(gain), int(splitk), *_lib.split_ws(), _lib.stream()))
+    return y
+
+
+def modconv_nba_raw(x, w, in_scale, out_scale, bias, noise, noise_w, slope, gain):
+    """StyledConv (plain 3x3 or 1x1) with its whole tail in the convolution's epilogue (g2s_modconv_nba /
+    g2s_conv3x3_wino_nba): gain * leaky_relu(out_scale * conv(in_scale * x) + noise_w * noise + bias, slope).
+    fp32 kernels only."""
+    _lib.require_cuda(x, w, in_scale, out_scale, bias, noise, noise_w)
+    if OPERANDS != "f32" or x.dtype != torch.float32:
+        raise RuntimeError("modconv_nba: fp32 kernels only")
+    x, w = x.contiguous(), w.contiguous()
+    B, C, H, W = x.shape
+    Cout, Cin, k, _ = w.shape
+    if C != Cin or tuple(noise.shape[-2:]) != (H, W) or noise.numel() != H * W:
+        raise RuntimeError("modconv_nba: shape mismatch")
+    si, so = in_scale.contiguous(), out_scale.contiguous()
+    bias, noise, noise_w = bias.contiguous(), noise.contiguous(), noise_w.contiguous()
+    L = _lib.load()
+    choice = wino_choice(x, w, PLAIN, 0, 1)
+    if choice is not None:
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        U = wino_weights(w, 0)
+        tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+        with profiled(2.0 * B * Cout * Cin * 9 * H * W, 4.0 * (x.numel() + w.numel() + y.numel()), 2.0 * 16 * tiles * Cout * Cin):
+            _lib.check(L.g2s_conv3x3_wino_nba(_lib.ptr(x), _lib.ptr(U), _lib.ptr(si), _lib.ptr(so), _lib.ptr(bias),
+                                              _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(y), B, Cin, Cout, H, W,
+                                              float(slope), float(gain), int(choice), *_lib.split_ws(), _lib.stream()))
+        return y
+    y = None
+    if L.g2s_modconv_needs_zero(B, Cin, Cout, H, W, k, PLAIN, 0, 1, 1) == 1:
+        y = _zp.take((B, Cout, H, W), x.device)
+    zeroed = y is not None
+    if y is None:
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    with profiled(2.0 * B * Cout * Cin * k * k * H * W, 4.0 * (x.numel() + w.numel() + y.numel())):
+        _lib.check(L.g2s_modconv_nba(_lib.ptr(x), _lib.ptr(w), _lib.ptr(si), _lib.ptr(so), _lib.ptr(bias), _lib.ptr(noise),
+                                     _lib.ptr(noise_w), _lib.ptr(y), B, Cin, Cout, H, W, k, PLAIN, 0, float(slope),
+                                     float(gain), int(zeroed), _lib.stream()))
     return y
 
 

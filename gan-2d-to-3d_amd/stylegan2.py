@@ -22,6 +22,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from . import synthesis
 from .modconv import DOWN2, PLAIN, UP2, conv2d, conv2d_supported, conv_bias_act, modconv, modconv_demod
 from .op import FusedLeakyReLU, add_bias_scale, fused_leaky_relu, fused_noise_bias_act, upfirdn2d
 
@@ -330,6 +331,8 @@ class StridedStyle(nn.ModuleList):
 class Generator(nn.Module):
     """model.py:398-627."""
 
+    ONE_NODE = True   # frozen generator on the GPU: the synthesis loop as ONE autograd node (synthesis._Synthesis)
+
     def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1],
                  lr_mlp=0.01):
         super().__init__()
@@ -491,6 +494,13 @@ class Generator(nn.Module):
             # one unbind instead of 2 * n_latent selects: the backward is a single stack, not a
             # zero-fill + copy + add per use (model.py:493-503 indexes latent[:, i] per layer)
             lat = self._batched_styles(latent.unbind(1))
+        if (self.ONE_NODE and not return_features and getattr(lat, 'pre', None) is not None
+                and synthesis.eligible(self, out, [p.s for p in lat.pre], noise)):
+            # the whole layer loop below as one autograd node with fused epilogues (synthesis.py)
+            image = synthesis.synthesize(self, noise, out, [p.s for p in lat.pre])
+            if return_latents:
+                return image, latent if latent is not None else self._per_layer_latents(styles, inject_index)
+            return image, None
         out = self.conv1(out, lat[0], noise=noise[0])
         skip = self.to_rgb1(out, lat[1])
         i = 1

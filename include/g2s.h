@@ -218,6 +218,14 @@ int g2s_noise_bias_act(const float *x, const float *noise, const float *noise_w,
 int g2s_upfirdn2d(const void *x, const float *k, void *y, int major, int in_h, int in_w, int kh,
                   int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
                   int pad_y0, int pad_y1, int dtype, g2s_stream_t stream);
+/* upfirdn2d (f32, one up / down factor for both axes) with the StyledConv tail of an UP-SAMPLING layer in its store
+ * (stylegan2-pytorch/model.py:264-275: conv_transpose2d, then Blur; :349-355: noise, bias, leaky ReLU):
+ *     y[m, oy, ox] = gain * leaky_relu(upfirdn2d(x)[m, oy, ox] + noise_w[0] * noise[oy, ox] + bias[m % channels], alpha)
+ * x [major = B * channels, in_h, in_w]; noise [out_h, out_w]; noise_w a DEVICE pointer to 1 float. */
+int g2s_upfirdn2d_nba(const float *x, const float *k, float *y, int major, int channels, int in_h, int in_w, int kh,
+                      int kw, int up, int down, int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float *bias,
+                      const float *noise, const float *noise_w, float alpha, float gain, g2s_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Modulated convolution (StyleGAN2 generator) as an fp32-MFMA implicit GEMM.
@@ -272,6 +280,14 @@ int g2s_modconv_ex(const float *x, const float *w, const float *in_scale, const 
                    int transpose, int act, float alpha, float gain, int y_is_zero, g2s_stream_t stream);
 int g2s_modconv_needs_zero(int B, int Cin, int Cout, int H, int W, int k, int mode, int transpose,
                            int has_scales, int fused);
+/* g2s_modconv_ex with the WHOLE StyledConv tail in the epilogue (stylegan2-pytorch/model.py:321-355: ModulatedConv2d,
+ * NoiseInjection, FusedLeakyReLU — the reference runs conv, `image + weight * noise` and fused_bias_act as three ops):
+ *     y = gain * leaky_relu(out_scale[b,o] * conv(in_scale * x)[b,o,h,w] + noise_w[0] * noise[h,w] + bias[o], alpha)
+ * noise [OH, OW] f32 (one map for all samples and channels), noise_w a DEVICE pointer to 1 float, bias [Cout].
+ * A split-K launch finishes with g2s_noise_bias_act in place. */
+int g2s_modconv_nba(const float *x, const float *w, const float *in_scale, const float *out_scale, const float *bias,
+                    const float *noise, const float *noise_w, float *y, int B, int Cin, int Cout, int H, int W, int k,
+                    int mode, int transpose, float alpha, float gain, int y_is_zero, g2s_stream_t stream);
 
 /* General 2-D convolution on the same fp32-MFMA implicit-GEMM kernel: the trained nets of the step
  * (depth / albedo / viewpoint / lighting / offset-encoder nets, GAN2Shape/networks.py:23-244:
@@ -386,6 +402,12 @@ int g2s_wino_weights(const float *w, float *U, int Cout, int Cin, int transpose,
 int g2s_conv3x3_wino(const float *x, const float *U, const float *in_scale, const float *out_scale,
                      const float *bias, float *y, int B, int Cr, int M, int H, int W, int act,
                      float alpha, float gain, int splitk, float *ws, int64_t ws_floats, g2s_stream_t stream);
+/* The same with the StyledConv tail in the epilogue (see g2s_modconv_nba): act = leaky-ReLU, bias / noise / noise_w
+ * required; the split-K and stream-K reduce passes add the noise term with the bias. */
+int g2s_conv3x3_wino_nba(const float *x, const float *U, const float *in_scale, const float *out_scale,
+                         const float *bias, const float *noise, const float *noise_w, float *y, int B, int Cr, int M,
+                         int H, int W, float alpha, float gain, int splitk, float *ws, int64_t ws_floats,
+                         g2s_stream_t stream);
 
 /* Tuning hook (tools/tune_modconv.py): force the tile configuration (0: 128x128, 1: 128x64,
  * 2: 64x64, 3: 32x128, 4: 64x128 output channels x pixels) and/or the split-K factor of the calling thread's following
@@ -413,6 +435,21 @@ int g2s_demod_bwd(const float *wsq, const float *s, const float *demod, const fl
  * gs = gs_add + (the above); gs_add [B, Cin] may be NULL, may alias gs.  Saves autograd's accumulation launch. */
 int g2s_demod_bwd_add(const float *wsq, const float *s, const float *demod, const float *gd, const float *gs_add,
                       float *gs, int B, int Cin, int Cout, g2s_stream_t stream);
+/* Backward of the frozen generator, one pass per activation x = gain * leaky_relu(yconv + noise_w * noise + bias)
+ * between two layers (stylegan2-pytorch/model.py:321-355,545-627; gan-2d-to-3d_amd/synthesis.py).  x is the output
+ * of the producer's StyledConv tail and the input of its consumers: the next modulated convolution (g1 = gradient
+ * w.r.t. s1 * x from its data-gradient GEMM) and, where present, ToRGB (g2, s2; all three NULL otherwise).
+ * Rows r = (b, c) of n = H * W:
+ *     dot1[r] = sum_i x g1,  dot2[r] = sum_i x g2                               (style gradients of the consumers)
+ *     out[r,i] = (g1 s1[r] + g2 s2[r]) * gain * (x > 0 ? 1 : slope)             (op/fused_act.py:33-38 with ref = x;
+ *                                                                                out may be NULL)
+ *     gdot[r]  = sum_i out * yconv / demod[r],  yconv = (x > 0 ? x : x / slope) / gain - noise_w[0] noise[i] - bias[c]
+ *                (d loss / d demodulation of the producer; gdot NULL: skipped, noise / bias / demod unused)
+ * x, g1, g2, out [rows, n] f32; s1, s2, demod, dot1, dot2, gdot [rows]; bias [channels], c = r % channels; noise [n]. */
+int g2s_synth_bwd_rows(const float *x, const float *g1, const float *s1, const float *g2, const float *s2,
+                       const float *noise, const float *noise_w, const float *bias, const float *demod, float *out,
+                       float *dot1, float *dot2, float *gdot, int rows, int channels, int n, float slope, float gain,
+                       g2s_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * LPIPS per-layer tail (csrc/lpips.hip): unit-normalise both feature maps over channels, weighted
