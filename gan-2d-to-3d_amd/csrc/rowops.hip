@@ -8,6 +8,7 @@
 //   g2s_demod_fwd/_bwd   demod[b,o] = rsqrt(sum_i wsq[o,i] * s[b,i]^2 + eps)
 //                        (ModulatedConv2d.forward, stylegan2-pytorch/model.py:254-258, with
 //                        weight = scale * W * style  =>  sum_{i,t} weight^2 = sum_i wsq[o,i] s[b,i]^2)
+#include <algorithm>
 #include "g2s_common.h"
 
 namespace g2s {
@@ -170,9 +171,104 @@ __global__ __launch_bounds__(256) void synth_rows(const float *__restrict__ x, c
     }
 }
 
+// The demodulations of ALL styled layers of the frozen generator in one launch each way (synthesis.py): the
+// styles of every layer are known before the first convolution, and every layer's two style-gradient inputs
+// (the convolution path's sum x * g and d loss / d demod) are complete when the backward pass ends.
+struct DemodMulti {
+    const float *wsq[G2S_DEMOD_MAX_LAYERS], *s[G2S_DEMOD_MAX_LAYERS], *gd[G2S_DEMOD_MAX_LAYERS];
+    float *demod[G2S_DEMOD_MAX_LAYERS], *gs[G2S_DEMOD_MAX_LAYERS];
+    int Cin[G2S_DEMOD_MAX_LAYERS], Cout[G2S_DEMOD_MAX_LAYERS];
+    int layers, B;
+    float eps;
+};
+
+__global__ __launch_bounds__(256) void demod_fwd_multi(DemodMulti d) {
+    const int l = blockIdx.y;
+    const int Cin = d.Cin[l], Cout = d.Cout[l];
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (idx >= d.B * Cout) return;
+    const int b = idx / Cout, o = idx % Cout;
+    const float *w = d.wsq[l] + (size_t)o * Cin, *sb = d.s[l] + (size_t)b * Cin;
+    float acc = 0.0f;
+    for (int i = lane; i < Cin; i += 64) acc += w[i] * sb[i] * sb[i];
+    acc = wave_sum(acc);
+    if (lane == 0) d.demod[l][idx] = 1.0f / sqrtf(acc + d.eps);
+}
+
+// grid (ceil(max Cin / 64), B, layers): demod_bwd of every layer, added in place to gs (the convolution path's sum)
+__global__ __launch_bounds__(256) void demod_bwd_multi(DemodMulti d) {
+    __shared__ float red[4][64];
+    const int l = blockIdx.z;
+    const int Cin = d.Cin[l], Cout = d.Cout[l];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane, b = blockIdx.y;
+    if (blockIdx.x * 64 >= Cin) return;      // whole workgroup: no barrier is skipped by part of it
+    const float *wsq = d.wsq[l], *demod = d.demod[l], *gd = d.gd[l];
+    float acc = 0.0f;
+    if (i < Cin) {
+#pragma unroll 8
+        for (int o = wave; o < Cout; o += 4) {
+            const float dm = demod[b * Cout + o];
+            acc += gd[b * Cout + o] * dm * dm * dm * wsq[(size_t)o * Cin + i];
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && i < Cin) {
+        const float g = -d.s[l][b * Cin + i] * (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+        d.gs[l][b * Cin + i] += g;
+    }
+}
+
 }  // namespace g2s
 
 using namespace g2s;
+
+static int demod_multi_fill(DemodMulti &d, const void *const *wsq, const void *const *s, const void *const *demod,
+                            const void *const *gd, const void *const *gs, const int *Cin, const int *Cout, int layers,
+                            int B, int &max_cin, int &max_cout) {
+    G2S_REQUIRE(layers > 0 && layers <= G2S_DEMOD_MAX_LAYERS && B > 0, "1..%d layers, B positive", G2S_DEMOD_MAX_LAYERS);
+    max_cin = max_cout = 0;
+    for (int l = 0; l < layers; l++) {
+        G2S_REQUIRE(wsq[l] && s[l] && demod[l] && Cin[l] > 0 && Cout[l] > 0, "layer %d: NULL pointer or empty", l);
+        d.wsq[l] = (const float *)wsq[l];
+        d.s[l] = (const float *)s[l];
+        d.demod[l] = (float *)demod[l];
+        d.gd[l] = gd ? (const float *)gd[l] : nullptr;
+        d.gs[l] = gs ? (float *)gs[l] : nullptr;
+        d.Cin[l] = Cin[l];
+        d.Cout[l] = Cout[l];
+        max_cin = std::max(max_cin, Cin[l]);
+        max_cout = std::max(max_cout, Cout[l]);
+    }
+    d.layers = layers;
+    d.B = B;
+    return G2S_OK;
+}
+
+extern "C" int g2s_demod_fwd_multi(const void *const *wsq, const void *const *s, const void *const *demod, const int *Cin,
+                                   const int *Cout, int layers, int B, float eps, g2s_stream_t stream) {
+    DemodMulti d{};
+    int mi, mo;
+    const int rc = demod_multi_fill(d, wsq, s, demod, nullptr, nullptr, Cin, Cout, layers, B, mi, mo);
+    if (rc != G2S_OK) return rc;
+    d.eps = eps;
+    demod_fwd_multi<<<dim3(cdiv((long)B * mo, 4), layers), 256, 0, as_stream(stream)>>>(d);
+    return check_launch("g2s_demod_fwd_multi");
+}
+
+extern "C" int g2s_demod_bwd_multi(const void *const *wsq, const void *const *s, const void *const *demod,
+                                   const void *const *gd, const void *const *gs, const int *Cin, const int *Cout,
+                                   int layers, int B, g2s_stream_t stream) {
+    G2S_REQUIRE(gd && gs, "gd, gs must not be NULL");
+    DemodMulti d{};
+    int mi, mo;
+    const int rc = demod_multi_fill(d, wsq, s, demod, gd, gs, Cin, Cout, layers, B, mi, mo);
+    if (rc != G2S_OK) return rc;
+    for (int l = 0; l < layers; l++) G2S_REQUIRE(gd[l] && gs[l], "layer %d: gd / gs NULL", l);
+    demod_bwd_multi<<<dim3(cdiv(mi, 64), B, layers), 256, 0, as_stream(stream)>>>(d);
+    return check_launch("g2s_demod_bwd_multi");
+}
 
 extern "C" int g2s_synth_bwd_rows(const float *x, const float *g1, const float *s1, const float *g2, const float *s2,
                                   const float *noise, const float *noise_w, const float *bias, const float *demod,

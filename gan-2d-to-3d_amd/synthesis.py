@@ -30,12 +30,32 @@ from .op.fused_act import add_bias_scale
 from .op.upfirdn2d import upfirdn2d, upfirdn2d_adjoint
 
 
-def _demod(wsq, s, eps):
-    B, Cin = s.shape
-    d = torch.empty((B, wsq.shape[0]), dtype=torch.float32, device=s.device)
-    _lib.check(_lib.load().g2s_demod_fwd(_lib.ptr(wsq), _lib.ptr(s), _lib.ptr(d), B, Cin, wsq.shape[0], float(eps),
-                                         _lib.stream()))
-    return d
+def _ptr_array(tensors):
+    return (_lib.C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _int_array(values):
+    return (_lib.C.c_int * len(values))(*[int(v) for v in values])
+
+
+def _demod_all(wsqs, styles, eps):
+    """demod[b,o] = rsqrt(sum_i wsq[o,i] s[b,i]^2 + eps) (model.py:254-258) of every styled layer: ONE launch."""
+    B = styles[0].shape[0]
+    demods = [torch.empty((B, w.shape[0]), dtype=torch.float32, device=w.device) for w in wsqs]
+    _lib.check(_lib.load().g2s_demod_fwd_multi(_ptr_array(wsqs), _ptr_array(styles), _ptr_array(demods),
+                                               _int_array([w.shape[1] for w in wsqs]), _int_array([w.shape[0] for w in wsqs]),
+                                               len(wsqs), B, float(eps), _lib.stream()))
+    return demods
+
+
+def _demod_bwd_all(entries):
+    """gs += (demodulation path) for every styled layer (entries: wsq, s, demod, gd, gs): ONE launch, in place."""
+    wsqs = [e[0] for e in entries]
+    B = entries[0][1].shape[0]
+    _lib.check(_lib.load().g2s_demod_bwd_multi(_ptr_array(wsqs), _ptr_array([e[1] for e in entries]),
+                                               _ptr_array([e[2] for e in entries]), _ptr_array([e[3] for e in entries]),
+                                               _ptr_array([e[4] for e in entries]), _int_array([w.shape[1] for w in wsqs]),
+                                               _int_array([w.shape[0] for w in wsqs]), len(entries), B, _lib.stream()))
 
 
 def _blur_nba(yc, blur, act, noise, nw):
@@ -67,14 +87,6 @@ def _rows(x, g1, s1, g2=None, s2=None, tail=None, demod=None, want_out=True):
     return out, dot1, dot2, gdot
 
 
-def _demod_bwd(wsq, s, demod, gd, gs_conv):
-    """gs = gs_conv + (demodulation path): g2s_demod_bwd_add, in place on gs_conv."""
-    B, Cin = s.shape
-    _lib.check(_lib.load().g2s_demod_bwd_add(_lib.ptr(wsq), _lib.ptr(s), _lib.ptr(demod), _lib.ptr(gd), _lib.ptr(gs_conv),
-                                             _lib.ptr(gs_conv), B, Cin, wsq.shape[0], _lib.stream()))
-    return gs_conv
-
-
 def _tail(sc, noise):
     a = sc.activate
     return (noise.contiguous(), sc.noise.weight.detach(), a.bias.detach(), a.negative_slope, a.scale)
@@ -89,13 +101,21 @@ class _Synthesis(Function):
         layers = []     # per StyledConv: dict(kind, sc, w, wsq, s, demod, x, yc, tail)
         rgbs = []       # per ToRGB: dict(tr, w, s, x)
         n = 0
+        # every styled layer's demodulation before the first convolution (the styles are all known): one launch
+        mods = [m for m, _ in G._style_layers()]
+        styled_pos = [i for i, m in enumerate(mods) if m.demodulate]
+        weights = {i: mods[i]._weights() for i in styled_pos}
+        eps = mods[styled_pos[0]].eps
+        assert all(mods[i].eps == eps for i in styled_pos)
+        demods = dict(zip(styled_pos, _demod_all([weights[i][1].contiguous() for i in styled_pos],
+                                                 [styles[i] for i in styled_pos], eps)))
 
         def styled(sc, x, nz, up):
             nonlocal n
             s = styles[n]
+            (w, wsq), demod = weights[n], demods[n]
+            assert mods[n] is sc.conv
             n += 1
-            w, wsq = sc.conv._weights()
-            demod = _demod(wsq, s, sc.conv.eps)
             tail = _tail(sc, nz)
             if up:
                 yc = modconv_raw(x, w, s, demod, UP2, 0)
@@ -103,7 +123,7 @@ class _Synthesis(Function):
             else:
                 yc = None
                 y = modconv_nba_raw(x, w, s, demod, tail[2], tail[0], tail[1], tail[3], tail[4])
-            layers.append(dict(up=up, sc=sc, w=w, wsq=wsq, s=s, demod=demod, x=x, yc=yc, y=y, tail=tail))
+            layers.append(dict(up=up, sc=sc, w=w, wsq=wsq.contiguous(), s=s, demod=demod, x=x, yc=yc, y=y, tail=tail))
             return y
 
         def to_rgb(tr, x, skip):
@@ -132,6 +152,7 @@ class _Synthesis(Function):
         g_rgb = g_img.contiguous()
         nxt = None                       # (gxs, s, layer) of the up-sampling convolution above the current level
         order = []                       # (position in the style list, gradient)
+        pending = []                     # (wsq, s, demod, gd, gs): the demodulation paths, added in ONE launch at the end
         # positions in the style list: conv1 0, to_rgb1 1, then (up, plain, rgb) triples
         li, ri = len(layers) - 1, len(rgbs) - 1
         while ri >= 0:
@@ -145,7 +166,8 @@ class _Synthesis(Function):
             else:
                 g_pre, dot_U, dot_T, gdot = _rows(a, nxt[0], nxt[1], gxs_rgb, T['s'], plain['tail'], plain['demod'])
                 U = nxt[2]
-                order.append((nxt[3], _demod_bwd(U['wsq'], U['s'], U['demod'], U['gd'], dot_U)))
+                order.append((nxt[3], dot_U))
+                pending.append((U['wsq'], U['s'], U['demod'], U['gd'], dot_U))
             order.append((pos_T, dot_T))
             if T['up']:
                 tr = T['tr']
@@ -155,11 +177,13 @@ class _Synthesis(Function):
             pos_P = 0 if ri == 0 else 3 * ri
             if ri == 0:                                          # conv1 reads the constant input: style gradient only
                 _, dot_P = rows_dot_scale(plain['x'], gxs_P, None, None, want_out=False, want_dot=True)
-                order.append((pos_P, _demod_bwd(plain['wsq'], plain['s'], plain['demod'], gdot, dot_P)))
+                order.append((pos_P, dot_P))
+                pending.append((plain['wsq'], plain['s'], plain['demod'], gdot, dot_P))
                 break
             up = layers[li - 1]
             g_pre_U, dot_P, _, _ = _rows(up['y'], gxs_P, plain['s'], None, None, up['tail'], None)
-            order.append((pos_P, _demod_bwd(plain['wsq'], plain['s'], plain['demod'], gdot, dot_P)))
+            order.append((pos_P, dot_P))
+            pending.append((plain['wsq'], plain['s'], plain['demod'], gdot, dot_P))
             # the up-sampling layer: Blur's adjoint, demodulation gradient from the saved transposed-conv output
             blur = up['sc'].conv.blur
             g_yc = upfirdn2d_adjoint(g_pre_U, blur.kernel, 1, 1, blur.pad, tuple(up['yc'].shape[2:]))
@@ -168,6 +192,7 @@ class _Synthesis(Function):
             nxt = (gxs_U, up['s'], up, 3 * ri - 1)
             li -= 2
             ri -= 1
+        _demod_bwd_all(pending)
         ctx.layers = ctx.rgbs = None
         out = [None] * (max(p for p, _ in order) + 1)
         for p, g in order:
