@@ -294,3 +294,119 @@ def test_thin_1x1_path_vs_oracle_and_mfma(L, B, cin, cout, H, W):
         _check(conv_bias_act(dev(x), dev(w), dev(b), PLAIN, 0.2, 2 ** 0.5), exp, cin, "MFMA path (forced tile)")
     finally:
         L.g2s_modconv_tune(-1, -1)
+
+
+# ----------------------------------------------------------------------------- StyledConv tail in the epilogue (round 4)
+def _nba_expected(pre, bias, noise, nw, alpha, gain):
+    v = pre + bias[None, :, None, None] + nw * noise[None, None]
+    return (np.where(v > 0, v, v * alpha) * gain).astype(np.float32)
+
+
+@pytest.mark.parametrize("B,cin,cout,H", [
+    (8, 128, 128, 128),    # G convs[9] (Winograd whole tiles; direct <128,128,18>)
+    (8, 512, 512, 16),     # G convs[3]: split-K / stream-K partitions
+    (8, 512, 512, 8),      # direct kernel by the measured table, split-K (deferred tail: g2s_noise_bias_act in place)
+    (8, 512, 512, 4),      # conv1 on the constant input
+    (3, 70, 130, 22),      # ragged channels, tiles spanning batch entries
+])
+def test_styledconv_tail_in_the_epilogue_vs_oracle(L, B, cin, cout, H):
+    """g2s_modconv_nba / g2s_conv3x3_wino_nba (modconv.modconv_nba_raw): the modulated 3x3 convolution with
+    NoiseInjection + FusedLeakyReLU in its epilogue (stylegan2-pytorch/model.py:321-355) against the C oracle's
+    convolution followed by the tail in numpy — every tile x split-K of the direct kernel, every partition of the
+    Winograd kernel (whole tiles, split-K with the reduce pass, stream-K with its reduce pass, atomics without a
+    workspace).  An activation input within the tolerance of zero may take the other slope: atol covers it."""
+    from gan2shape_amd import lib, modconv as mc
+    rng = np.random.default_rng(B + cin + cout + H + 4)
+    x = rng.standard_normal((B, cin, H, H)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+    s_in = (1 + 0.3 * rng.standard_normal((B, cin))).astype(np.float32)
+    s_out = (1 + 0.3 * rng.standard_normal((B, cout))).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    noise = rng.standard_normal((H, H)).astype(np.float32)
+    nw, alpha, gain = 0.37, 0.2, 2 ** 0.5
+    exp = _nba_expected(expected_modconv(x, w, s_in, s_out, PLAIN, 0), bias, noise, nw, alpha, gain)
+    args = (dev(x), dev(w), dev(s_in), dev(s_out), dev(bias), dev(noise).view(1, 1, H, H), dev(np.array([nw], np.float32)), alpha, gain)
+    K = cin * 9
+    saved = (mc.WINOGRAD, mc.WINO_FORCE)
+    try:
+        L.g2s_modconv_tune(-1, -1)
+        _check(mc.modconv_nba_raw(*args), exp, K, "built-in choice")
+        if H >= 8:
+            mc.WINOGRAD = True
+            for sk in (0, 1, 3, -7, -256):
+                mc.WINO_FORCE = sk
+                _check(mc.modconv_nba_raw(*args), exp, K, f"winograd partition {sk}")
+            real = lib.split_ws
+            lib.split_ws = lambda: (None, 0)       # no workspace: float atomics + the deferred tail
+            try:
+                mc.WINO_FORCE = 3
+                _check(mc.modconv_nba_raw(*args), exp, K, "winograd split-K 3, atomics")
+            finally:
+                lib.split_ws = real
+        mc.WINO_FORCE = "direct"
+        for tile, sk in [(-1, -1)] + [(t, s) for t in TILES for s in SPLITS]:
+            assert L.g2s_modconv_tune(tile, sk) == 0
+            _check(mc.modconv_nba_raw(*args), exp, K, f"direct tile {tile} split-K {sk}")
+    finally:
+        L.g2s_modconv_tune(-1, -1)
+        mc.WINOGRAD, mc.WINO_FORCE = saved
+
+
+@pytest.mark.parametrize("B,C,H", [(8, 128, 129), (2, 512, 9), (3, 20, 35), (2, 8, 67)])
+def test_blur_with_the_styledconv_tail_vs_oracle(L, B, C, H):
+    """g2s_upfirdn2d_nba: the Blur behind an up-sampling StyledConv's transposed convolution (model.py:264-275;
+    kernel [1,3,3,1] x 4, pad (1, 1)) with noise + bias + leaky ReLU in its store, against the C oracle's
+    upfirdn2d and the tail in numpy."""
+    from oracle import capi
+    from gan2shape_amd import lib, stylegan2 as sg2
+    rng = np.random.default_rng(B + C + H)
+    x = rng.standard_normal((B, C, H, H)).astype(np.float32)
+    k = (sg2.make_kernel([1, 3, 3, 1]) * 4).numpy().astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32)
+    nw, alpha, gain = -0.8, 0.2, 2 ** 0.5
+    pre = capi.upfirdn2d(x, k, (1, 1), (1, 1), (1, 1, 1, 1))
+    oh = pre.shape[2]
+    noise = rng.standard_normal((oh, oh)).astype(np.float32)
+    exp = _nba_expected(pre, bias, noise, nw, alpha, gain)
+    y = torch.empty((B, C, oh, oh), device="cuda")
+    xd, kd, bd, nd, nwd = dev(x), dev(k), dev(bias), dev(noise), dev(np.array([nw], np.float32))
+    lib.check(L.g2s_upfirdn2d_nba(lib.ptr(xd), lib.ptr(kd), lib.ptr(y), B * C, C, H, H, 4, 4, 1, 1, 1, 1, 1, 1,
+                                  lib.ptr(bd), lib.ptr(nd), lib.ptr(nwd), alpha, gain, lib.stream()))
+    np.testing.assert_allclose(y.cpu().numpy(), exp, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,C,H,two,with_gdot", [(8, 128, 128, True, True), (3, 20, 4, False, True), (2, 7, 9, True, False),
+                                                 (2, 512, 16, False, False)])
+def test_synth_bwd_rows_vs_float64(L, B, C, H, two, with_gdot):
+    """g2s_synth_bwd_rows against the chain it replaces, in float64 torch: the consumers' style gradients
+    sum_hw x * g, the gated joined gradient (g1 s1 + g2 s2) * gain * (x > 0 ? 1 : slope), and the producer's
+    demodulation gradient sum_hw out * yconv / demod with yconv recovered from x."""
+    from gan2shape_amd import lib
+    torch.manual_seed(B + C + H)
+    slope, gain, nw = 0.2, 2 ** 0.5, 0.6
+    yconv = torch.randn(B, C, H, H, dtype=torch.float64)
+    noise, bias = torch.randn(H, H, dtype=torch.float64), torch.randn(C, dtype=torch.float64)
+    pre = yconv + nw * noise + bias.view(1, C, 1, 1)
+    x = torch.where(pre > 0, pre, pre * slope) * gain
+    g1, g2 = torch.randn_like(x), torch.randn_like(x)
+    s1, s2, demod = torch.randn(B, C, dtype=torch.float64), torch.randn(B, C, dtype=torch.float64), 0.5 + torch.rand(B, C, dtype=torch.float64)
+    joined = g1 * s1[:, :, None, None] + (g2 * s2[:, :, None, None] if two else 0)
+    out_ref = joined * torch.where(x > 0, gain, gain * slope)
+    f = lambda t: None if t is None else t.float().cuda().contiguous()      # noqa: E731
+    xd, g1d, g2d = f(x), f(g1), f(g2) if two else None
+    s1d, s2d, nzd, nwd, bd, dmd = f(s1), f(s2) if two else None, f(noise), f(torch.tensor([nw])), f(bias), f(demod)   # kept alive
+    out = torch.empty_like(xd)
+    dot1, dot2, gdot = (torch.empty(B, C, device="cuda") for _ in range(3))
+    lib.check(L.g2s_synth_bwd_rows(lib.ptr(xd), lib.ptr(g1d), lib.ptr(s1d), lib.ptr(g2d), lib.ptr(s2d),
+                                   lib.ptr(nzd), lib.ptr(nwd), lib.ptr(bd), lib.ptr(dmd),
+                                   lib.ptr(out), lib.ptr(dot1), lib.ptr(dot2 if two else None),
+                                   lib.ptr(gdot if with_gdot else None), B * C, C, H * H, slope, gain, lib.stream()))
+    scale = float(out_ref.abs().max())
+    assert float((out.double().cpu() - out_ref).abs().max()) <= 2e-6 * scale
+    n = H * H
+    np.testing.assert_allclose(dot1.double().cpu().numpy(), (x * g1).sum((2, 3)).numpy(), rtol=1e-4, atol=2e-5 * n ** 0.5)
+    if two:
+        np.testing.assert_allclose(dot2.double().cpu().numpy(), (x * g2).sum((2, 3)).numpy(), rtol=1e-4, atol=2e-5 * n ** 0.5)
+    if with_gdot:
+        ref = (out_ref * yconv).sum((2, 3)) / demod
+        np.testing.assert_allclose(gdot.double().cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4 * n ** 0.5)
