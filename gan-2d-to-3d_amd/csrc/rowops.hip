@@ -171,6 +171,22 @@ __global__ __launch_bounds__(256) void synth_rows(const float *__restrict__ x, c
     }
 }
 
+// out[c] = sum_{b, i} g[b, c, i]: the bias gradient of a convolution (nn.Conv2d(bias=True) of the offset encoder's
+// residual blocks, GAN2Shape/networks.py:170-244) — torch's generic reduction over dims (0, 2, 3) takes 15-23 us on
+// these few-KB tensors.  One workgroup per channel, fixed summation order.
+__global__ __launch_bounds__(256) void channel_sum(const float *__restrict__ g, float *__restrict__ out, int B, int C,
+                                                   int n) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.0f;
+    const int total = B * n;
+    for (int i = threadIdx.x; i < total; i += 256) acc += g[((size_t)(i / n) * C + c) * n + i % n];
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = red[0] + red[1] + red[2] + red[3];
+}
+
 // The demodulations of ALL styled layers of the frozen generator in one launch each way (synthesis.py): the
 // styles of every layer are known before the first convolution, and every layer's two style-gradient inputs
 // (the convolution path's sum x * g and d loss / d demod) are complete when the backward pass ends.
@@ -268,6 +284,12 @@ extern "C" int g2s_demod_bwd_multi(const void *const *wsq, const void *const *s,
     for (int l = 0; l < layers; l++) G2S_REQUIRE(gd[l] && gs[l], "layer %d: gd / gs NULL", l);
     demod_bwd_multi<<<dim3(cdiv(mi, 64), B, layers), 256, 0, as_stream(stream)>>>(d);
     return check_launch("g2s_demod_bwd_multi");
+}
+
+extern "C" int g2s_channel_sum(const float *g, float *out, int B, int C, int n, g2s_stream_t stream) {
+    G2S_REQUIRE(g && out && B > 0 && C > 0 && n > 0 && (long)B * n < (1l << 31), "bad argument");
+    channel_sum<<<C, 256, 0, as_stream(stream)>>>(g, out, B, C, n);
+    return check_launch("g2s_channel_sum");
 }
 
 extern "C" int g2s_synth_bwd_rows(const float *x, const float *g1, const float *s1, const float *g2, const float *s2,

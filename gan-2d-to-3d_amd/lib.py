@@ -50,6 +50,7 @@ SIGNATURES = {
     "g2s_conv3x3_wino_nba": (_i, [_p] * 8 + [_i] * 5 + [_f, _f, _i, _p, _i64, _p]),
     "g2s_upfirdn2d_nba": (_i, [_p, _p, _p] + [_i] * 12 + [_p, _p, _p, _f, _f, _p]),
     "g2s_synth_bwd_rows": (_i, [_p] * 13 + [_i, _i, _i, _f, _f, _p]),
+    "g2s_channel_sum": (_i, [_p, _p, _i, _i, _i, _p]),
     "g2s_demod_fwd_multi": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "g2s_demod_bwd_multi": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "g2s_modconv_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p]),

@@ -201,7 +201,9 @@ class ConvFunction(Function):
             gw = (_wgrad(x, gy, k, stride, pad, out, groups) if transposed
                   else _wgrad(gy, x, k, stride, pad, out, groups))
         if has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3))
+            gb = torch.empty(gy.shape[1], dtype=torch.float32, device=gy.device)     # gy.sum((0, 2, 3)), one small launch
+            _lib.check(_lib.load().g2s_channel_sum(_lib.ptr(gy), _lib.ptr(gb), gy.shape[0], gy.shape[1],
+                                                   gy.shape[2] * gy.shape[3], _lib.stream()))
         return gx, gw, gb, None, None, None, None, None, None
 
 

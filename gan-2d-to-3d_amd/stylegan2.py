@@ -24,7 +24,7 @@ from torch.nn import functional as F
 
 from . import synthesis
 from .modconv import DOWN2, PLAIN, UP2, conv2d, conv2d_supported, conv_bias_act, modconv, modconv_demod
-from .op import FusedLeakyReLU, add_bias_scale, fused_leaky_relu, fused_noise_bias_act, upfirdn2d
+from .op import FusedLeakyReLU, add_bias_scale, clamp, fused_leaky_relu, fused_noise_bias_act, upfirdn2d
 
 
 class PixelNorm(nn.Module):
@@ -445,7 +445,7 @@ class Generator(nn.Module):
         offset, latent = latent_projection
         gan_im, _ = self([latent], input_is_w=True, truncation_latent=mean_latent,
                          truncation=truncation, randomize_noise=False)
-        return gan_im.clamp(min=-1, max=1), offset
+        return clamp(gan_im, -1, 1), offset      # gan_im.clamp(min=-1, max=1): one launch each way
 
     def invert(self, image, latent_projection, truncation, mean_latent, batchify=0):
         """model.py:523-534 (the reference's batchify branch passes image slices to invert_sub and

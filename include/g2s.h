@@ -435,6 +435,9 @@ int g2s_demod_bwd(const float *wsq, const float *s, const float *demod, const fl
  * gs = gs_add + (the above); gs_add [B, Cin] may be NULL, may alias gs.  Saves autograd's accumulation launch. */
 int g2s_demod_bwd_add(const float *wsq, const float *s, const float *demod, const float *gd, const float *gs_add,
                       float *gs, int B, int Cin, int Cout, g2s_stream_t stream);
+/* out[c] = sum over b and i of g[b, c, i] — the bias gradient of nn.Conv2d(bias=True) (the offset encoder's residual
+ * blocks, GAN2Shape/networks.py:170-244; autograd's sum over dims (0, 2, 3)).  g [B, C, n], out [C] f32; fixed order. */
+int g2s_channel_sum(const float *g, float *out, int B, int C, int n, g2s_stream_t stream);
 /* g2s_demod_fwd / g2s_demod_bwd_add of up to G2S_DEMOD_MAX_LAYERS layers in ONE launch each (the styled layers of
  * the frozen generator, synthesis.py): HOST arrays of `layers` device pointers / sizes; layer l has wsq [Cout_l,
  * Cin_l], s [B, Cin_l], demod [B, Cout_l], gd [B, Cout_l]; the backward ADDS its result to gs [B, Cin_l] in place. */

@@ -315,3 +315,16 @@ def test_generator_one_node_equals_op_by_op(g2s, size, batch):
     with torch.no_grad():          # the no-grad forward (sample generation) takes the same node
         img2, _ = G([w0], input_is_w=True, randomize_noise=False)
     assert float((img2 - img1).abs().max()) <= 2e-6 * float(img1.abs().max())
+
+
+def test_channel_sum_is_the_bias_gradient(g2s):
+    """g2s_channel_sum = gy.sum((0, 2, 3)) (the bias gradient of the offset encoder's biased convolutions)."""
+    from gan2shape_amd import lib
+    L = lib.load()
+    torch.manual_seed(0)
+    for shape in [(8, 512, 4, 4), (8, 64, 32, 32), (3, 7, 5, 9), (1, 1, 1, 1), (8, 1024, 1, 1)]:
+        gy = torch.randn(*shape, device="cuda")
+        out = torch.empty(shape[1], device="cuda")
+        lib.check(L.g2s_channel_sum(lib.ptr(gy), lib.ptr(out), shape[0], shape[1], shape[2] * shape[3], lib.stream()))
+        ref = gy.double().sum((0, 2, 3))
+        assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), shape
