@@ -33,6 +33,10 @@
 //     (one wave per SIMD issues in order: whatever is not between two MFMAs stalls the matrix pipe);
 //     V double-buffered in LDS, U in a ring of three (its DMA runs two tiles ahead), one raw
 //     s_barrier per K tile.
+//   * Two waves per SIMD (the positions of a block split over two waves, 128 accumulator registers each) was built
+//     and measured in round 4: correct, 1.16 - 1.27x slower — the bare loop of two waves sharing the matrix pipe
+//     (16 MFMAs + 8 fragment reads each, nothing else) takes as long per K tile as this kernel's complete loop
+//     (profiles/r04_experiments_dropped.txt).
 //   * Partition: whole tiles, split-K, or stream-K (equal runs of (tile, K tile) units over 256
 //     workgroups, a run may cross tile borders; partial sums meet by float atomics in a cleared y).
 #include <algorithm>
