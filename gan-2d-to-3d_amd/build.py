@@ -36,6 +36,7 @@ SOURCES = {
     "groupnorm.hip": [],
     "conv_wgrad.hip": [],
     "adam.hip": [],
+    "probe.hip": [],
 }
 # The kernels take their descriptor struct by value.  Clang copies such a parameter into a private
 # alloca and relies on InstCombine to fold the copy back onto the (constant) kernarg segment — a

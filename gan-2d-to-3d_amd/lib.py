@@ -55,6 +55,8 @@ SIGNATURES = {
     "g2s_demod_bwd_multi": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "g2s_modconv_f16": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
     "g2s_modconv_tune": (_i, [_i, _i]),
+    "g2s_mfma_probe": (_i, [_p, _i, _i, _i, _p]),
+    "g2s_mfma_lds_probe": (_i, [_p, _i, _i, _i, _i, _p]),
     "g2s_wino_weights_floats": (_sz, [_i, _i]),
     "g2s_wino_weights": (_i, [_p, _p, _i, _i, _i, _p]),
     "g2s_conv3x3_wino": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p, _i64, _p]),

@@ -409,6 +409,14 @@ int g2s_conv3x3_wino_nba(const float *x, const float *U, const float *in_scale, 
                          int H, int W, float alpha, float gain, int splitk, float *ws, int64_t ws_floats,
                          g2s_stream_t stream);
 
+/* Measurement aid (csrc/probe.hip, tools/bench_mfma_peak.py), not part of the training path: `blocks` workgroups of
+ * `waves` wavefronts (1..8), each issuing iters x 8 independent v_mfma_f32_32x32x2_f32 from registers — what the fp32
+ * matrix pipe sustains against the nominal 157.3 TFLOP/s the rooflines use.  FLOP = blocks * waves * iters * 8 * 4096. */
+int g2s_mfma_probe(float *out, int blocks, int waves, int iters, g2s_stream_t stream);
+/* The same with the Winograd inner loop's operand traffic: 8 x 16-byte LDS reads per lane per 16 MFMAs; acc_agpr = 1
+ * forces the accumulators into AccVGPRs.  FLOP = blocks * waves * iters * 16 * 4096. */
+int g2s_mfma_lds_probe(float *out, int blocks, int waves, int iters, int acc_agpr, g2s_stream_t stream);
+
 /* Tuning hook (tools/tune_modconv.py): force the tile configuration (0: 128x128, 1: 128x64,
  * 2: 64x64, 3: 32x128, 4: 64x128 output channels x pixels) and/or the split-K factor of the calling thread's following
  * g2s_modconv / g2s_conv_bias_act / g2s_conv2d launches (slices of the deepest polyphase class of a
