@@ -131,9 +131,74 @@ __global__ __launch_bounds__(WL1_THREADS) void wl1_bwd2(const float *__restrict_
     }
 }
 
+// One launch for a level of the discriminator-feature loss's backward (losses._DFeatureL1):
+//     gx      = (gadd + gadd2) * add_scale + sign(x - y) * w * g[0] / den[0]
+//               (the residual join (a + b) / sqrt(2) of the block above, stylegan2-pytorch/model.py:693-697, with this
+//                level's masked-L1 gradient; x == NULL: no L1 term; gadd / gadd2 may be NULL)
+//     gx_gate = gx * gain * (gate_ref > 0 ? 1 : slope)      (FusedLeakyReLU's backward of the block's conv2, optional)
+__global__ __launch_bounds__(WL1_THREADS) void wl1_bwd3(const float *__restrict__ x, const float *__restrict__ y,
+                                                        const float *__restrict__ w, const float *__restrict__ g,
+                                                        const float *__restrict__ den, const float *__restrict__ gadd,
+                                                        const float *__restrict__ gadd2, float add_scale,
+                                                        float *__restrict__ gx, const float *__restrict__ gate_ref,
+                                                        float slope, float gain, float *__restrict__ gx_gate, int C,
+                                                        int HW4, long total4) {
+    const float k = x ? g[0] / den[0] : 0.0f;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *y4 = reinterpret_cast<const float4 *>(y);
+    const float4 *w4 = reinterpret_cast<const float4 *>(w), *a4 = reinterpret_cast<const float4 *>(gadd);
+    const float4 *b4 = reinterpret_cast<const float4 *>(gadd2), *r4 = reinterpret_cast<const float4 *>(gate_ref);
+    float4 *g4 = reinterpret_cast<float4 *>(gx), *q4 = reinterpret_cast<float4 *>(gx_gate);
+    for (long i = (long)blockIdx.x * WL1_THREADS + threadIdx.x; i < total4; i += (long)gridDim.x * WL1_THREADS) {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x) {
+            const float4 a = x4[i], b = y4[i];
+            float4 m = make_float4(k, k, k, k);
+            if (w) {
+                const long plane = i / HW4;
+                const float4 ww = w4[(plane / C) * HW4 + (i - plane * HW4)];
+                m = make_float4(ww.x * k, ww.y * k, ww.z * k, ww.w * k);
+            }
+            auto sgn = [](float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); };
+            r = make_float4(sgn(a.x - b.x) * m.x, sgn(a.y - b.y) * m.y, sgn(a.z - b.z) * m.z, sgn(a.w - b.w) * m.w);
+        }
+        if (gadd) {
+            float4 e = a4[i];
+            if (gadd2) {
+                const float4 f = b4[i];
+                e = make_float4(e.x + f.x, e.y + f.y, e.z + f.z, e.w + f.w);
+            }
+            r = make_float4(e.x * add_scale + r.x, e.y * add_scale + r.y, e.z * add_scale + r.z, e.w * add_scale + r.w);
+        }
+        if (gx) g4[i] = r;
+        if (gx_gate) {
+            const float4 f = r4[i];
+            const float lo = gain * slope;
+            q4[i] = make_float4(r.x * (f.x > 0.0f ? gain : lo), r.y * (f.y > 0.0f ? gain : lo),
+                                r.z * (f.z > 0.0f ? gain : lo), r.w * (f.w > 0.0f ? gain : lo));
+        }
+    }
+}
+
 }  // namespace g2s
 
 using namespace g2s;
+
+extern "C" int g2s_weighted_l1_bwd3(const float *x, const float *y, const float *w, const float *g, const float *den,
+                                    const float *gadd, const float *gadd2, float add_scale, float *gx,
+                                    const float *gate_ref, float slope, float gain, float *gx_gate, int B, int C, int HW,
+                                    g2s_stream_t stream) {
+    G2S_REQUIRE(B > 0 && C > 0 && HW > 0 && HW % 4 == 0, "sizes must be positive, HW a multiple of 4");
+    G2S_REQUIRE(!x || (y && g && den), "the L1 term needs x, y, g and den");
+    G2S_REQUIRE(x || gadd, "nothing to compute");
+    G2S_REQUIRE(!gadd2 || gadd, "gadd2 needs gadd");
+    G2S_REQUIRE(gx || gx_gate, "no output");
+    G2S_REQUIRE((gx_gate == nullptr) == (gate_ref == nullptr), "gx_gate and gate_ref come together");
+    const long total4 = (long)B * C * HW / 4;
+    const int blocks = (int)std::min<long>(cdiv(total4, WL1_THREADS * 4), 4096);
+    wl1_bwd3<<<blocks, WL1_THREADS, 0, as_stream(stream)>>>(x, y, w, g, den, gadd, gadd2, add_scale, gx, gate_ref, slope,
+                                                            gain, gx_gate, C, HW / 4, total4);
+    return check_launch("g2s_weighted_l1_bwd3");
+}
 
 static int wl1_check(const void *x, const void *y, int B, int C, int HW) {
     G2S_REQUIRE(x && y, "NULL pointer argument");

@@ -280,3 +280,4 @@ extern "C" int g2s_upfirdn2d_nba(const float *x, const float *k, float *y, int m
     return upfirdn2d_launch(x, k, y, major, in_h, in_w, kh, kw, up, up, down, down, pad_x0, pad_x1, pad_y0, pad_y1,
                             G2S_F32, stream, channels, bias, noise, noise_w, alpha, gain);
 }
+

@@ -77,6 +77,7 @@ SIGNATURES = {
     "g2s_weighted_l1_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_weighted_l1_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_weighted_l1_fwd2": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "g2s_weighted_l1_bwd3": (_i, [_p] * 7 + [_f, _p, _p, _f, _f, _p, _i, _i, _i, _p]),
     "g2s_weighted_l1_bwd2": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "g2s_view_transform_fwd": (_i, [_p, _f, _f, _f, _p, _p, _i, _p]),
     "g2s_view_transform_bwd": (_i, [_p, _f, _f, _f, _p, _p, _p, _i, _p]),

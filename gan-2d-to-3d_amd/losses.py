@@ -68,6 +68,8 @@ class _DFeatureL1(torch.autograd.Function):
               and the residual join (a + b) / sqrt(2) as one launch.
     Same arithmetic as DiscriminatorLoss.__call__'s op-by-op form below."""
 
+    FUSED_LEVELS = True        # join + masked-L1 gradient + conv2's gate as one launch per level (g2s_weighted_l1_bwd3)
+
     @staticmethod
     def forward(ctx, fake, real, D, count, weights):
         from . import lib as _lib
@@ -106,35 +108,55 @@ class _DFeatureL1(torch.autograd.Function):
         L = _lib.load()
         N = ctx.N
         slope, gain = 0.2, 2 ** 0.5
-        g = None
         g_total = g_total.contiguous()
+
+        def level_grad(feat, wc, den, add, ref):
+            """(gx, gx * gate(ref)) of one launch (g2s_weighted_l1_bwd3): this level's masked-L1 gradient w.r.t. the fake
+            half + the residual join (a + b) / sqrt(2) of the block above; the gated copy feeds the block's conv2."""
+            shape = ref.shape
+            gx = torch.empty(shape, dtype=torch.float32, device=ref.device) if feat is not None else None
+            gg = torch.empty(shape, dtype=torch.float32, device=ref.device)
+            a0, a1 = (None, None) if add is None else add
+            _lib.check(L.g2s_weighted_l1_bwd3(
+                _lib.ptr(None if feat is None else feat[:N]), _lib.ptr(None if feat is None else feat[N:]), _lib.ptr(wc),
+                _lib.ptr(g_total if feat is not None else None), _lib.ptr(den), _lib.ptr(a0), _lib.ptr(a1), 2 ** -0.5,
+                _lib.ptr(gx), _lib.ptr(ref), slope, gain, _lib.ptr(gg), shape[0], shape[1], shape[2] * shape[3], _lib.stream()))
+            return gx, gg
+
+        add = None          # (gx_main, gx_skip) of the block above: joined inside the next level's launch
         for level in range(len(ctx.blocks) - 1, -1, -1):
             blk, in_hw, y1, y2, feat, wc = ctx.blocks[level]
-            # masked L1 of this level, gradient w.r.t. the fake half, added to what arrives from the next level
-            B2, C, H, W = feat.shape
-            gl = torch.empty((N, C, H, W), dtype=torch.float32, device=feat.device)
-            _lib.check(L.g2s_weighted_l1_bwd2(_lib.ptr(feat[:N]), _lib.ptr(feat[N:]), _lib.ptr(wc), _lib.ptr(g_total),
-                                              _lib.ptr(ctx.numden[level, 1:]), _lib.ptr(g), _lib.ptr(gl), N, C, H * W,
-                                              _lib.stream()))
-            g = gl
+            if _DFeatureL1.FUSED_LEVELS:
+                g, g2 = level_grad(feat, wc, ctx.numden[level, 1:], add, y2[:N])
+            else:
+                joined = None if add is None else add_bias_scale(add[0], add[1], None, 2 ** -0.5)
+                g = torch.empty(y2[:N].shape, dtype=torch.float32, device=feat.device)
+                _lib.check(L.g2s_weighted_l1_bwd2(_lib.ptr(feat[:N]), _lib.ptr(feat[N:]), _lib.ptr(wc), _lib.ptr(g_total),
+                                                  _lib.ptr(ctx.numden[level, 1:]), _lib.ptr(joined), _lib.ptr(g), N,
+                                                  feat.shape[1], feat.shape[2] * feat.shape[3], _lib.stream()))
+                g2 = relu_gate(g, y2[:N], slope, gain)
             # out = (conv2(conv1(x)) + skip(x)) / sqrt(2): both branches keep the common factor, the join applies it
             conv2, conv1, skip = blk.conv2, blk.conv1, blk.skip
             w2 = conv2[-2]._w.get(conv2[-2].weight, conv2[-2].scale)
             w1 = conv1[-2]._w.get(conv1[-2].weight, conv1[-2].scale)
             ws = skip[-1]._w.get(skip[-1].weight, skip[-1].scale)
-            g2 = relu_gate(g, y2[:N], slope, gain)
             gb = modconv_raw(g2, w2, None, None, DOWN2, 1)                       # w.r.t. the blurred conv1 output
             blur2 = conv2[0]
-            gy1 = upfirdn2d_adjoint(gb, blur2.kernel, 1, blur2.down, blur2.pad, y1.shape[2:])
-            g1 = relu_gate(gy1, y1[:N], slope, gain)
+            # (conv1's gate in the store of the Blur's adjoint — a g2s_upfirdn2d_gate — was built and measured 0.03 ms
+            # SLOWER per step 2 than the separate gate launch: the per-output reference load stalls the blur's store
+            # phase; removed again)
+            g1 = relu_gate(upfirdn2d_adjoint(gb, blur2.kernel, 1, blur2.down, blur2.pad, y1.shape[2:]), y1[:N], slope, gain)
             gx_main = modconv_raw(g1, w1, None, None, PLAIN, 1)
             gs = modconv_raw(g, ws, None, None, PLAIN, 1)                        # 1x1 on the blur-downsampled input
             blurs = skip[0]
             gx_skip = upfirdn2d_adjoint(gs, blurs.kernel, 1, blurs.down, blurs.pad, in_hw)
-            g = add_bias_scale(gx_main, gx_skip, None, 2 ** -0.5)
+            add = (gx_main, gx_skip)
         first = ctx.first
         w0 = first[-2]._w.get(first[-2].weight, first[-2].scale)
-        g0 = relu_gate(g, ctx.y0[:N], slope, gain)
+        if _DFeatureL1.FUSED_LEVELS:
+            _, g0 = level_grad(None, None, None, add, ctx.y0[:N].contiguous())      # the last join + the first layer's gate
+        else:
+            g0 = relu_gate(add_bias_scale(add[0], add[1], None, 2 ** -0.5), ctx.y0[:N], slope, gain)
         gx = modconv_raw(g0, w0, None, None, PLAIN, 1)
         return gx, None, None, None, None
 

@@ -227,6 +227,7 @@ int g2s_upfirdn2d_nba(const float *x, const float *k, float *y, int major, int c
                       const float *noise, const float *noise_w, float alpha, float gain, g2s_stream_t stream);
 
 
+
 /* ------------------------------------------------------------------------------------------
  * Modulated convolution (StyleGAN2 generator) as an fp32-MFMA implicit GEMM.
  * Replaces the grouped F.conv2d / F.conv_transpose2d inside ModulatedConv2d.forward
@@ -510,6 +511,14 @@ int g2s_weighted_l1_fwd2(const float *x, const float *y, const float *w, float *
                          g2s_stream_t stream);
 int g2s_weighted_l1_bwd2(const float *x, const float *y, const float *w, const float *g, const float *den,
                          const float *gadd, float *gx, int B, int C, int HW, g2s_stream_t stream);
+/* One launch per level of the discriminator-feature loss's backward (losses._DFeatureL1; GAN2Shape/losses.py:11-36 on
+ * stylegan2-pytorch/model.py:679-697):  gx = (gadd + gadd2) * add_scale + [x != NULL] sign(x - y) w g[0] / den[0] — the
+ * residual join of the block above with this level's masked-L1 gradient — and, optionally, gx_gate = gx * gain *
+ * (gate_ref > 0 ? 1 : slope), the gradient behind the block's activated conv2.  Any of gadd2, gx, gx_gate may be NULL. */
+int g2s_weighted_l1_bwd3(const float *x, const float *y, const float *w, const float *g, const float *den,
+                         const float *gadd, const float *gadd2, float add_scale, float *gx, const float *gate_ref,
+                         float slope, float gain, float *gx_gate, int B, int C, int HW, g2s_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Fused renderer geometry / loss glue (csrc/geometry.hip).  All f32, device pointers; K is a HOST
