@@ -26,6 +26,7 @@ SOURCES = {
     "thinconv.hip": [],
     # packed f32 VALU (v_pk_*) beside MFMAs costs more than it saves (MI355X_MICROARCH.md): no SLP packing
     "winograd.hip": ["-fno-slp-vectorize"],
+    "winograd4.hip": ["-fno-slp-vectorize"],
     "split_reduce.hip": [],
     "rowops.hip": [],
     "lpips.hip": [],
@@ -67,7 +68,8 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(LIBDIR, name.replace(".hip", ".o"))
         if force or _newer(src, obj, headers):
-            jobs.append([hipcc] + COMMON + extra + ["-c", src, "-o", obj])
+            dev = os.environ.get("G2S_HIPFLAGS_" + name.split(".")[0].upper(), "").split()   # measurement builds
+            jobs.append([hipcc] + COMMON + extra + dev + ["-c", src, "-o", obj])
         objs.append(obj)
     relink = force or bool(jobs)
     if jobs:

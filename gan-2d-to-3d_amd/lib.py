@@ -58,6 +58,10 @@ SIGNATURES = {
     "g2s_mfma_probe": (_i, [_p, _i, _i, _i, _p]),
     "g2s_mfma_lds_probe": (_i, [_p, _i, _i, _i, _i, _p]),
     "g2s_wino_weights_floats": (_sz, [_i, _i]),
+    "g2s_wino4_weights_floats": (_sz, [_i, _i]),
+    "g2s_wino4_weights": (_i, [_p, _p, _i, _i, _i, _p]),
+    "g2s_wino4_supported": (_i, [_i] * 5),
+    "g2s_conv3x3_wino4": (_i, [_p] * 8 + [_i] * 6 + [_f, _f, _i, _p, _i64, _p]),
     "g2s_wino_weights": (_i, [_p, _p, _i, _i, _i, _p]),
     "g2s_conv3x3_wino": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p, _i64, _p]),
     "g2s_conv2d": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_i, _f, _f, _i, _p]),

@@ -135,17 +135,71 @@ def wino_weights(w, transpose):
     return hit[1]
 
 
-def _wino_launch(x, w, in_scale, out_scale, bias, transpose, act, alpha, gain, y, splitk=0):
+# Winograd F(4x4, 3x3) (csrc/winograd4.hip) for the large maps: 1.78x fewer MFMA operations than F(2x2).
+# WINO4 = False keeps every Winograd layer on F(2x2); WINO4_FORCE (tests / tools): "on" = whenever the kernel
+# supports the shape, "off", or None = the built-in choice below.
+WINO4 = True
+WINO4_FORCE = None
+WINO4_SPLITK = 0    # tests / tools: the kernel's splitk argument (0 = library choice)
+WINO4_MIN_BLOCKS = 128   # 64-channel x 32-tile workgroups below which F(2x2)'s stream-K partition fills the chip better
+_WINO4_U = {}
+
+
+def wino4_choice(B, Cr, M, H, W):
+    """True: this 3x3 stride-1 launch goes to the F(4x4, 3x3) kernel."""
+    if WINO4_FORCE == "off" or not (WINO4 or WINO4_FORCE == "on"):
+        return False
+    if _lib.load().g2s_wino4_supported(B, Cr, M, H, W) != 1:
+        return False
+    if WINO4_FORCE == "on":
+        return True
+    blocks = (M // 64) * -(-(B * (H // 4) * (W // 4)) // 32)
+    return blocks >= WINO4_MIN_BLOCKS and Cr >= 64
+
+
+def wino4_weights(w, transpose):
+    """U = G g G^T (6x6 per channel pair) of a constant weight tensor in the F(4x4) kernel's tiled layout."""
+    key = (w.data_ptr(), w._version, tuple(w.shape), int(transpose))
+    hit = _WINO4_U.get(key)
+    if hit is None:
+        if len(_WINO4_U) > 256:
+            _WINO4_U.clear()
+        Cout, Cin = w.shape[:2]
+        L = _lib.load()
+        M, Cr = (Cin, Cout) if transpose else (Cout, Cin)
+        U = torch.empty(L.g2s_wino4_weights_floats(M, Cr), dtype=torch.float32, device=w.device)
+        _lib.check(L.g2s_wino4_weights(_lib.ptr(w), _lib.ptr(U), Cout, Cin, int(transpose), _lib.stream()))
+        hit = _WINO4_U[key] = (w, U)
+    return hit[1]
+
+
+def _wino_launch(x, w, in_scale, out_scale, bias, transpose, act, alpha, gain, y, splitk=0, noise=None, noise_w=None):
+    """One stride-1 3x3 launch on a Winograd kernel: F(4x4) where wino4_choice says so, else F(2x2) with the
+    partition `splitk`.  noise / noise_w: the StyledConv tail (then bias and act = 1 are required)."""
     B, Cr, H, W = x.shape
     M = y.shape[1]
-    U = wino_weights(w, transpose)
     L = _lib.load()
+    flop, nbytes = 2.0 * B * M * Cr * 9 * H * W, 4.0 * (x.numel() + w.numel() + y.numel())
+    if wino4_choice(B, Cr, M, H, W):
+        U = wino4_weights(w, transpose)
+        with profiled(flop, nbytes, 2.0 * 36 * B * (H // 4) * (W // 4) * M * Cr):
+            _lib.check(L.g2s_conv3x3_wino4(_lib.ptr(x), _lib.ptr(U), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                           _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(y), B, Cr, M, H, W,
+                                           int(act), float(alpha), float(gain), int(WINO4_SPLITK), *_lib.split_ws(),
+                                           _lib.stream()))
+        return y
+    U = wino_weights(w, transpose)
     tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
-    with profiled(2.0 * B * M * Cr * 9 * H * W, 4.0 * (x.numel() + w.numel() + y.numel()),
-                  2.0 * 16 * tiles * M * Cr):
-        _lib.check(L.g2s_conv3x3_wino(_lib.ptr(x), _lib.ptr(U), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                      _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W, int(act), float(alpha),
-                                      float(gain), int(splitk), *_lib.split_ws(), _lib.stream()))
+    with profiled(flop, nbytes, 2.0 * 16 * tiles * M * Cr):
+        if noise is not None:
+            _lib.check(L.g2s_conv3x3_wino_nba(_lib.ptr(x), _lib.ptr(U), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                              _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(y), B, Cr, M,
+                                              H, W, float(alpha), float(gain), int(splitk), *_lib.split_ws(),
+                                              _lib.stream()))
+        else:
+            _lib.check(L.g2s_conv3x3_wino(_lib.ptr(x), _lib.ptr(U), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                          _lib.ptr(bias), _lib.ptr(y), B, Cr, M, H, W, int(act), float(alpha),
+                                          float(gain), int(splitk), *_lib.split_ws(), _lib.stream()))
     return y
 
 
@@ -167,13 +221,7 @@ def modconv_nba_raw(x, w, in_scale, out_scale, bias, noise, noise_w, slope, gain
     choice = wino_choice(x, w, PLAIN, 0, 1)
     if choice is not None:
         y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
-        U = wino_weights(w, 0)
-        tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
-        with profiled(2.0 * B * Cout * Cin * 9 * H * W, 4.0 * (x.numel() + w.numel() + y.numel()), 2.0 * 16 * tiles * Cout * Cin):
-            _lib.check(L.g2s_conv3x3_wino_nba(_lib.ptr(x), _lib.ptr(U), _lib.ptr(si), _lib.ptr(so), _lib.ptr(bias),
-                                              _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(y), B, Cin, Cout, H, W,
-                                              float(slope), float(gain), int(choice), *_lib.split_ws(), _lib.stream()))
-        return y
+        return _wino_launch(x, w, si, so, bias, 0, 1, slope, gain, y, choice, noise, noise_w)
     y = None
     if L.g2s_modconv_needs_zero(B, Cin, Cout, H, W, k, PLAIN, 0, 1, 1) == 1:
         y = _zp.take((B, Cout, H, W), x.device)

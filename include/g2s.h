@@ -410,6 +410,26 @@ int g2s_conv3x3_wino_nba(const float *x, const float *U, const float *in_scale, 
                          int H, int W, float alpha, float gain, int splitk, float *ws, int64_t ws_floats,
                          g2s_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The same map as Winograd F(4x4, 3x3) (csrc/winograd4.hip): 36 multiplications per 16 outputs — 1.78x fewer than
+ * g2s_conv3x3_wino, 4x fewer than the direct form — for the large maps of the frozen networks.  Interpolation points
+ * 0, +-1, +-2, inf; U in double arithmetic, one rounding; fp32 everywhere else (error bound and measurements: DESIGN §4.3b).
+ * g2s_wino4_supported: 1 when the kernel takes the shape (H, W multiples of 4, W / 4 divides 32, M a multiple of 64,
+ *   Cr a multiple of 4); the caller falls back to g2s_conv3x3_wino otherwise.
+ * g2s_wino4_weights / _floats: as g2s_wino_weights, in this kernel's own tiled layout.
+ * g2s_conv3x3_wino4: y[b,m] = act(out_scale[b,m] * sum_c conv3x3(in_scale[b,c] * x[b,c], w(m,c)) + noise_w[0] *
+ *   noise[h,w] + bias[m]); in_scale, out_scale, bias, noise (+ noise_w) may be NULL.  splitk = 0: whole tiles, or K
+ *   slices through the workspace `ws` (as above) when whole tiles would leave CUs idle; splitk > 0: that split (needs
+ *   ws; falls back to whole tiles without one).  No atomics on any path: sums have a fixed order.
+ * ---------------------------------------------------------------------------------------- */
+size_t g2s_wino4_weights_floats(int M, int Cr);
+int g2s_wino4_weights(const float *w, float *U, int Cout, int Cin, int transpose, g2s_stream_t stream);
+int g2s_wino4_supported(int B, int Cr, int M, int H, int W);
+int g2s_conv3x3_wino4(const float *x, const float *U, const float *in_scale, const float *out_scale,
+                      const float *bias, const float *noise, const float *noise_w, float *y, int B, int Cr, int M,
+                      int H, int W, int act, float alpha, float gain, int splitk, float *ws, int64_t ws_floats,
+                      g2s_stream_t stream);
+
 /* Measurement aid (csrc/probe.hip, tools/bench_mfma_peak.py), not part of the training path: `blocks` workgroups of
  * `waves` wavefronts (1..8), each issuing iters x 8 independent v_mfma_f32_32x32x2_f32 from registers — what the fp32
  * matrix pipe sustains against the nominal 157.3 TFLOP/s the rooflines use.  FLOP = blocks * waves * iters * 8 * 4096. */
