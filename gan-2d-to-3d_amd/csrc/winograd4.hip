@@ -16,18 +16,27 @@
 // per element) and the four partial 4x4 output tiles meet in LDS.
 //   * Workgroup = 64 output channels x 32 tiles (512 output pixels per channel), 8 waves: wave
 //     (g, q) owns channel half g and quadrant q: 9 accumulators of v_mfma_f32_32x32x2_f32 = 144
-//     registers -> TWO waves per SIMD (256 registers each), the staging of one overlaps the MFMAs of
-//     the other without hand placement.
+//     registers -> TWO waves per SIMD (256 registers each): group 0 stages first and multiplies after,
+//     group 1 the other way round, so the two waves of a SIMD take turns on the matrix pipe and the vector
+//     ALU without hand placement.
 //   * U = G g G^T once per weight tensor (computed in double, rounded once) in the tiled layout
 //     [m-tile][k-tile][g][position][channel pair][32 m][2]: a K tile (4 channels) of an m-tile is one
-//     contiguous 36 KB block in LDS order -> direct DMA (global_load_lds_dwordx4), ring of three.
-//   * V = B^T d B in registers: a thread owns (tile, channel, half of the transform rows): five
-//     aligned 16-byte loads (the tile's own 4 columns of 5 patch rows), the two outer columns from the
-//     neighbour lanes (whole-wave DPP shifts), 18 values to LDS.  The two wave groups alternate: group
-//     k mod 2 stages K tile k while the other requests its next patch and the next U block.
-//   * One ds_read_b64 per operand and position feeds two MFMAs (channels 2 kk, 2 kk + 1).
+//     contiguous 36 KB block in LDS order -> 36 LDS-DMA pieces of 1 KB, ring of two.
+//   * The input patches go through LDS raw: per K tile the 6 rows x 4 own columns of every (tile, channel)
+//     patch are fetched ONCE (12 LDS-DMA pieces; rows outside the image come from a zero row), two stages.
+//     A thread then transforms one 3x3 quadrant of V = B^T d B for one (tile, channel): five 16-byte LDS
+//     reads (a 5x5 corner of the patch; the outer column from the neighbour lane by a whole-wave DPP
+//     shift), 48 VALU operations, 9 values to the V stage.  (Loading the corners from global memory
+//     instead — 3.3x the bytes — ran at the same speed: the K tile is paced by how long its 48 KB of
+//     requests take to land within ONE iteration)
+//   * Every transfer is an LDS-DMA request issued from inline assembly; the one s_waitcnt vmcnt(0) before the
+//     hand-over barrier states their completion (the compiler would add vmcnt(0) before every DS instruction
+//     after a __builtin_amdgcn_global_load_lds it cannot prove disjoint).
+//   * One ds_read_b64 per operand and position feeds two MFMAs (channels 2 kk, 2 kk + 1); after the barrier
+//     the fragments of the next tile are read under the last four MFMAs of this one.
+//   * Partition: whole tiles, or K slices through a workspace + split_reduce (no atomics: fixed summation
+//     order on every path).
 #include <algorithm>
-#include <cstdlib>
 #include "g2s_common.h"
 #include "split_reduce.h"
 #include "xcd_tile.h"
@@ -37,7 +46,6 @@ namespace g2s {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int W4BM = 64;        // output channels per workgroup
 constexpr int W4BT = 32;        // 4x4 output tiles per workgroup
@@ -45,12 +53,6 @@ constexpr int W4KC = 4;         // channels per K tile
 constexpr int W4THREADS = 512;
 constexpr int W4UBLOCK = 36 * W4KC * W4BM;   // floats of one (m-tile, k-tile) block of U
 constexpr int W4VBLOCK = 36 * W4KC * W4BT;
-#ifndef W4VAR
-#define W4VAR 0
-#endif
-#ifndef W4DBG
-#define W4DBG 0   // ablation switches of the K loop (measurement builds only)
-#endif
 
 struct Wino4Desc {
     const float *x, *U, *in_scale, *out_scale, *bias, *noise, *noise_w;
@@ -96,121 +98,114 @@ __device__ __forceinline__ void at3(bool hi, float m0, float m1, float m2, float
     }
 }
 
+// 16 bytes of zeros: the source of the patch rows above / below the image
+__device__ __attribute__((aligned(16))) float w4_zero_row[4] = {0.f, 0.f, 0.f, 0.f};
+
+// LDS (floats): U ring of two K tiles | V, two stages | raw patch rows, two stages | the style scales of the image
+constexpr int W4RAW = 12 * 64 * 4;                 // 4 channels x 3 row pairs x (32 tiles x 2 rows) x 4 columns
+constexpr int W4_LU = 0, W4_LV = 2 * W4UBLOCK, W4_LR = W4_LV + 2 * W4VBLOCK, W4_LS = W4_LR + 2 * W4RAW;
+constexpr int W4MAXC = 512;                        // reduction channels whose scales fit the LDS table
+constexpr int W4LDS = W4_LS + W4MAXC;
+
 template <bool SCALE>
 __global__ __launch_bounds__(W4THREADS) void wino4_kernel(Wino4Desc d) {
-    // U ring of three, DMA two tiles ahead.  Three VARIABLES, not one array: the compiler makes a DS instruction
-    // wait for every outstanding LDS-DMA request it cannot prove disjoint from it (vmcnt(0) at the next
-    // fragment read would turn the ring into a synchronous copy); distinct LDS variables carry alias scopes, so
-    // with the K loop unrolled by three the reads of one slot do not wait for the DMA into another.
-    __shared__ __attribute__((aligned(16))) float U0[W4UBLOCK];
-    __shared__ __attribute__((aligned(16))) float U1[W4UBLOCK];
-    __shared__ __attribute__((aligned(16))) float U2[W4UBLOCK];
-    __shared__ __attribute__((aligned(16))) float Vs[2 * W4VBLOCK];
+    __shared__ __attribute__((aligned(16))) float L[W4LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;     // channel half of the MFMA block and staging group
+    const int grp = wave >> 2;     // channel half of the MFMA block; staging order (0: stage first, 1: multiply first)
     const int quad = wave & 3;     // positions i in 3 (quad >> 1) .. + 2, j in 3 (quad & 1) .. + 2
     const int l31 = lane & 31, lk = lane >> 5;
     const int tiles_m = d.M / W4BM;
-    const int per_img = d.TH * d.TW, Ntiles = d.B * per_img;
+    const int per_img = d.TH * d.TW;
     const int g = xcd_logical_tile();
     const int mt = g % tiles_m, nt = g / tiles_m;
     const int per = (d.ktiles + d.splitk - 1) / d.splitk;
     const int kt_begin = blockIdx.y * per;
     const int n_it = min(d.ktiles, kt_begin + per) - kt_begin;
     const int HW = d.H * d.W;
-    constexpr int OOB = 0x7fffffff;
+    // the 32 tiles of a block lie in ONE image (per_img % 32 == 0, checked by the host)
+    const int img = (nt * W4BT) / per_img;
+    const int tile0 = nt * W4BT - img * per_img;
 
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)d.x, 0, d.B * d.Cr * HW * 4, 0x00020000);
-    const auto rsc = __builtin_amdgcn_make_buffer_rsrc((void *)(SCALE ? d.in_scale : d.x), 0,
-                                                       SCALE ? d.B * d.Cr * 4 : 4, 0x00020000);
+    // Every global -> LDS transfer is an LDS-DMA request in inline assembly: the compiler does not see
+    // them, so it adds no waits of its own (with __builtin_amdgcn_global_load_lds every later DS instruction
+    // that may alias waits for ALL outstanding requests, vmcnt(0), which makes the copy synchronous); their
+    // completion is stated once per K tile by the s_waitcnt vmcnt(0) before the hand-over barrier.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(&L[0]);
+    auto dma16 = [&](unsigned lds_float, const char *gp) {
+        const unsigned la = lds0 + lds_float * 4;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
+    };
+    // ---- requests.  48 pieces of 1 KB per K tile: 36 of U, 12 of raw patch rows; 6 per wave.
+    //   U block (m-tile, K tile): contiguous 36 KB in LDS order; waves 0..3 take pieces 3 w .. 3 w + 2, waves
+    //     4..7 pieces 12 + 6 (w - 4) .. + 5.
+    //   raw rows: piece c = 3 channel + row pair; lane = tile + 32 (row & 1); waves 0..3 take c = w, w + 4, w + 8.
+    const char *ubase = reinterpret_cast<const char *>(d.U) + (size_t)mt * d.ktiles * W4UBLOCK * 4 + lane * 16;
+    auto dma_u = [&](int kt, int slot) {
+        const int first = wave < 4 ? 3 * wave : 12 + 6 * (wave - 4), cnt = wave < 4 ? 3 : 6;
+#pragma unroll
+        for (int e = 0; e < 6; e++)
+            if (e < cnt) dma16(W4_LU + slot * W4UBLOCK + (first + e) * 256, ubase + (size_t)kt * W4UBLOCK * 4 + (first + e) * 1024);
+    };
+    // per-lane sources of the three raw pieces of this wave (waves 0..3): piece c = wave + 4 e
+    const char *rsrc[3];
+    bool rok[3];
+    {
+        const int n = tile0 + l31, ty = n / d.TW, tx = n % d.TW;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const int c = (wave & 3) + 4 * e, ch = c / 3, rp = c % 3;
+            const int iy = 4 * ty - 1 + 2 * rp + lk;
+            rok[e] = iy >= 0 && iy < d.H;
+            rsrc[e] = rok[e] ? reinterpret_cast<const char *>(d.x + ((size_t)(img * d.Cr + ch) * d.H + iy) * d.W + 4 * tx)
+                             : reinterpret_cast<const char *>(w4_zero_row);
+        }
+    }
+    auto dma_raw = [&](int kt, int st) {
+        if (wave < 4) {
+#pragma unroll
+            for (int e = 0; e < 3; e++)
+                dma16(W4_LR + st * W4RAW + ((wave & 3) + 4 * e) * 256, rsrc[e] + (rok[e] ? (size_t)kt * W4KC * HW * 4 : 0));
+        }
+    };
 
     // ---- staging role: tile l31 of the block, channel sc of the K tile, rows 3 sh .. + 2 and columns 3 sq .. + 2
     // of V = B^T d B (one 3x3 quadrant of the 6x6 positions: it needs a 5x5 corner of the 6x6 patch)
     const int sc = 2 * (wave & 1) + lk;
     const int sh = (wave >> 1) & 1;
     const int sq = grp;
-    int offD[5];
-    int offS = OOB;
     bool edge_col;   // the outer patch column this thread needs lies outside the image
     {
-        const int n = nt * W4BT + l31;
-        const bool valid = n < Ntiles;
-        const int b = valid ? n / per_img : 0, r = valid ? n % per_img : 0;
-        const int ty = r / d.TW, tx = r % d.TW;
-        const int base = (b * d.Cr + sc) * HW;
+        const int tx = (tile0 + l31) % d.TW;
         edge_col = sq ? tx == d.TW - 1 : tx == 0;
-#pragma unroll
-        for (int i = 0; i < 5; i++) {   // rows 0..4 of the patch (sh = 0) or 1..5 (sh = 1)
-            const int iy = 4 * ty - 1 + sh + i;
-            offD[i] = (valid & (iy >= 0) & (iy < d.H)) ? (base + iy * d.W + 4 * tx) * 4 : OOB;
-        }
-        if (valid) offS = (b * d.Cr + sc) * 4;
     }
-    const char *ubase = reinterpret_cast<const char *>(d.U) + (size_t)mt * d.ktiles * W4UBLOCK * 4 + lane * 16;
-    // this wave's share of the U block of K tile kt -> ring slot: five 1 KB chunks wave, wave + 8, ..  (36 chunks
-    // over 8 waves: waves 4..7 request chunk 35 a second time — every wave has the SAME number of requests in
-    // flight, which lets the compiler count them: its waits for the patch rows then leave the U requests alone)
-    auto dma_u = [&](int kt, float *slot) {
-#pragma unroll
-        for (int e = 0; e < 5; e++) {
-            const int chunk = min(e * 8 + wave, 35);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(ubase + (size_t)kt * W4UBLOCK * 4 + chunk * 1024),
-                (__attribute__((address_space(3))) void *)(slot + chunk * 256), 16, 0, 0);
-        }
-    };
-    u32x4 rd[5];
-    float rs = 1.0f;
-    // row i of the patch corner (i = 0..4), i = 5: the style scale
-    auto load_patch1 = [&](int kt, const int i) {
-        if ((W4DBG & 128) && i >= 3 && i < 5) rd[i] = rd[i - 3];
-        else if (i < 5) rd[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, offD[i], kt * W4KC * HW * 4, 0);
-        else if constexpr (SCALE) rs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsc, offS, kt * W4KC * 4, 0));
-    };
-    auto load_patch = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) load_patch1(kt, i);
-    };
-    // the quadrant of B^T d B of the registers -> stage `st` of V, layout [position][channel pair][tile][2]
-    auto stage_patch = [&](int st) {
+    // the quadrant of B^T d B of raw stage `rst` -> stage `st` of V, layout [position][channel pair][tile][2]
+    auto stage_patch = [&](int kt, int rst, int st) {
+        const f32x4 *raw = reinterpret_cast<const f32x4 *>(&L[W4_LR + rst * W4RAW]);
         float t[5][3];
-        if (sq == 0) {   // columns 0..2 of V from patch columns -1..3: the left one from lane - 1
 #pragma unroll
-            for (int i = 0; i < 5; i++) {
-                const int nb = __builtin_amdgcn_mov_dpp((int)rd[i].w, 0x138, 0xf, 0xf, true);
-                bt_lo3(edge_col ? 0.0f : __builtin_bit_cast(float, nb), __uint_as_float(rd[i].x), __uint_as_float(rd[i].y),
-                       __uint_as_float(rd[i].z), __uint_as_float(rd[i].w), t[i]);
-            }
-        } else {         // columns 3..5 of V from patch columns 0..4: the right one from lane + 1
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                const int nb = __builtin_amdgcn_mov_dpp((int)rd[i].x, 0x130, 0xf, 0xf, true);
-                bt_hi3(__uint_as_float(rd[i].x), __uint_as_float(rd[i].y), __uint_as_float(rd[i].z), __uint_as_float(rd[i].w),
-                       edge_col ? 0.0f : __builtin_bit_cast(float, nb), t[i]);
-            }
+        for (int i = 0; i < 5; i++) {
+            const int r = sh + i;                                    // patch row
+            const f32x4 v = raw[(sc * 3 + (r >> 1)) * 64 + l31 + 32 * (r & 1)];
+            // outer columns from the neighbour lanes = neighbour tiles of the tile row (whole-wave DPP shifts);
+            // (__float_as_int, not __builtin_bit_cast: bit_cast of a vector ELEMENT reads element 0 with this compiler)
+            const int nl = __builtin_amdgcn_mov_dpp(__float_as_int(v.w), 0x138, 0xf, 0xf, true);   // lane - 1
+            const int nr = __builtin_amdgcn_mov_dpp(__float_as_int(v.x), 0x130, 0xf, 0xf, true);   // lane + 1
+            if (sq == 0)   // columns 0..2 of V from patch columns -1..3
+                bt_lo3(edge_col ? 0.0f : __builtin_bit_cast(float, nl), v.x, v.y, v.z, v.w, t[i]);
+            else           // columns 3..5 of V from patch columns 0..4
+                bt_hi3(v.x, v.y, v.z, v.w, edge_col ? 0.0f : __builtin_bit_cast(float, nr), t[i]);
         }
-        float *vw = &Vs[0] + st * W4VBLOCK + ((sh * 2 + sq) * 9) * 128 + (sc >> 1) * 64 + l31 * 2 + (sc & 1);
-        float o[3][3];
-        if (sh == 0) {
+        const float rs = SCALE ? L[W4_LS + kt * W4KC + sc] : 1.0f;
+        float *vw = &L[W4_LV + st * W4VBLOCK + ((sh * 2 + sq) * 9) * 128 + (sc >> 1) * 64 + l31 * 2 + (sc & 1)];
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                float c3[3];
-                bt_lo3(t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], c3);
-                o[0][j] = c3[0], o[1][j] = c3[1], o[2][j] = c3[2];
-            }
-        } else {
+        for (int j = 0; j < 3; j++) {
+            float c3[3];
+            if (sh == 0) bt_lo3(t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], c3);
+            else bt_hi3(t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], c3);
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                float c3[3];
-                bt_hi3(t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], c3);
-                o[0][j] = c3[0], o[1][j] = c3[1], o[2][j] = c3[2];
-            }
+            for (int i = 0; i < 3; i++) vw[(i * 3 + j) * 128] = c3[i] * rs;
         }
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) vw[(i * 3 + j) * 128] = o[i][j] * rs;
     };
 
     f32x16 acc[9];
@@ -219,21 +214,22 @@ __global__ __launch_bounds__(W4THREADS) void wino4_kernel(Wino4Desc d) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[p][r] = 0.0f;
 
-    // ---- prologue: tile 0 staged, U of tiles 0 and 1 and the patch of tile 1 requested
-    dma_u(kt_begin, U0);
-    load_patch(kt_begin);
-    stage_patch(0);
-    if (n_it > 1) {
-        load_patch(kt_begin + 1);
-        dma_u(kt_begin + 1, U1);
+    // ---- prologue: U(0), raw(0), raw(1), the image's style scales; tile 0 staged
+    dma_u(kt_begin, 0);
+    dma_raw(kt_begin, 0);
+    if (n_it > 1) dma_raw(kt_begin + 1, 1);
+    if constexpr (SCALE) {
+        if (tid < d.Cr) L[W4_LS + tid] = d.in_scale[(size_t)img * d.Cr + tid];
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    stage_patch(kt_begin, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     const int foff = lk * 64 + l31 * 2;
     f32x2 fa[9], fb[9];
-    auto read_frags = [&](const float *slot, int st, const int p0, const int p1) {
-        const float *ua = slot + (grp * 36 + quad * 9) * 128 + foff;
-        const float *vb = &Vs[0] + st * W4VBLOCK + (quad * 9) * 128 + foff;
+    auto read_frags = [&](int slot, int st, const int p0, const int p1) {
+        const float *ua = &L[W4_LU + slot * W4UBLOCK + (grp * 36 + quad * 9) * 128 + foff];
+        const float *vb = &L[W4_LV + st * W4VBLOCK + (quad * 9) * 128 + foff];
 #pragma unroll
         for (int p = p0; p < p1; p++) {
             fa[p] = *reinterpret_cast<const f32x2 *>(ua + p * 128);
@@ -241,62 +237,42 @@ __global__ __launch_bounds__(W4THREADS) void wino4_kernel(Wino4Desc d) {
         }
     };
     auto mfmas = [&](const int p0, const int p1) {
-        if (W4DBG & 2) return;
 #pragma unroll
         for (int p = p0; p < p1; p++) {
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p].x, fb[p].x, acc[p], 0, 0, 0);
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p].y, fb[p].y, acc[p], 0, 0, 0);
         }
     };
-    read_frags(U0, 0, 0, 9);
-    // One K tile.  Every wave stages its quadrant of tile it + 1 and requests tile it + 2 (patch corner into the
-    // registers the staging has released, then its chunks of U into the ring slot tile it - 1 has left).  The two
-    // waves of a SIMD (one of each group) take turns on the matrix pipe and the vector ALU: group 0 stages FIRST
-    // and multiplies after, group 1 the other way round.  Positions 0..6, hand-over barrier, then the fragments
-    // of tile it + 1 go into the registers positions 0..6 have released, under the MFMAs of positions 7, 8.
-    // Before the barrier a wave's chunks of U(it + 1) — requested one iteration ago — must have landed: the
-    // counted vmcnt leaves exactly this iteration's requests in flight (they have until the NEXT barrier).
-    auto k_tile = [&](int it, const float *Unext, float *Ureq) {
-        const bool more = it + 1 < n_it, req2 = it + 2 < n_it;
-        auto stage_and_request = [&]() {
-            if (more && !(W4DBG & 1)) stage_patch((it + 1) & 1);
-            if (req2) {
-                if (!(W4DBG & 8)) load_patch(kt_begin + it + 2);
-                if (!(W4DBG & 4)) dma_u(kt_begin + it + 2, Ureq);
-            }
-        };
-        if (grp == 0) stage_and_request();
+    read_frags(0, 0, 0, 9);
+    // One K tile per iteration, one barrier.  Between barrier it - 1 and barrier it every wave
+    //   * requests U(it + 1) into the ring slot tile it - 1 has left and the raw rows of tile it + 2 into the
+    //     stage tile it has left (6 pieces per wave; they land before barrier it: vmcnt(0)),
+    //   * stages its quadrant of tile it + 1 from the raw rows barrier it - 1 has published,
+    //   * multiplies positions 0..6 of tile it.
+    // The two waves of a SIMD (one of each group) take turns on the matrix pipe and the vector ALU: group 0
+    // stages FIRST and multiplies after, group 1 the other way round.  After the barrier the fragments of tile
+    // it + 1 go into the registers positions 0..6 have released, under the MFMAs of positions 7, 8.
+    for (int it = 0; it < n_it; it++) {
+        const bool more = it + 1 < n_it;
+        const int kt = kt_begin + it;
+        if (more) dma_u(kt + 1, (it + 1) & 1);
+        if (it + 2 < n_it) dma_raw(kt + 2, it & 1);
+        if (grp == 0 && more) stage_patch(kt + 1, (it + 1) & 1, (it + 1) & 1);
         mfmas(0, 7);
-        if (grp != 0) stage_and_request();
-        if (!req2 || (W4DBG & 12)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {   // 5 patch rows (+ scale) + 5 chunks of U
-            if constexpr (SCALE) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        }
-        if (!(W4DBG & 64)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (more && !(W4DBG & 32)) read_frags(Unext, (it + 1) & 1, 0, 7);
+        if (grp != 0 && more) stage_patch(kt + 1, (it + 1) & 1, (it + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (more) read_frags((it + 1) & 1, (it + 1) & 1, 0, 7);
         mfmas(7, 9);
-        if (more && !(W4DBG & 32)) read_frags(Unext, (it + 1) & 1, 7, 9);
-    };
-    for (int it = 0; it < n_it; it += 3) {
-        k_tile(it, U1, U2);
-        if (it + 1 < n_it) k_tile(it + 1, U2, U0);
-        if (it + 2 < n_it) k_tile(it + 2, U0, U1);
+        if (more) read_frags((it + 1) & 1, (it + 1) & 1, 7, 9);
     }
-    __syncthreads();   // the last tile's fragment reads are done before the exchange buffer reuses the ring
+    __syncthreads();   // the last tile's fragment reads are done before the exchange buffer reuses the LDS
 
     // ---- epilogue: partial output transform of this wave's quadrant, the four partial 4x4 tiles meet in
     // LDS (wave `quad` owns output row `quad` of every tile), scale / bias / noise / activation, store.
     // C layout of the 32x32 MFMA: row m = (r & 3) + 8 (r >> 2) + 4 lk, column n = l31.
-    if (W4DBG & 16) return;
     const bool qi = quad >> 1, qj = quad & 1;
-    // exchange buffer [grp][dest row a][source slot 3][rr 4][lane 64] of float4: 8 (grp, a) blocks of 12 KB,
-    // three per ring slot
-    auto X = [&](int ga) -> f32x4 * {
-        float *base = ga < 3 ? U0 : ga < 6 ? U1 : U2;
-        return reinterpret_cast<f32x4 *>(base) + (ga % 3) * 768;
-    };
+    f32x4 *X = reinterpret_cast<f32x4 *>(&L[0]);   // exchange buffer [grp][dest row a][source slot 3][rr 4][lane 64]
+    const int Ntiles = d.B * per_img;
     const int n = nt * W4BT + l31;
     const bool valid = n < Ntiles;
     const int b = valid ? n / per_img : 0, rr_ = valid ? n % per_img : 0;
@@ -329,7 +305,7 @@ __global__ __launch_bounds__(W4THREADS) void wino4_kernel(Wino4Desc d) {
             for (int a = 0; a < 4; a++) {
                 const f32x4 v{Y[a][0], Y[a][1], Y[a][2], Y[a][3]};
                 if (a == quad) own[rr] = v;
-                else X(grp * 4 + a)[((((quad - a) & 3) - 1) * 4 + rr) * 64 + lane] = v;
+                else X[(((grp * 4 + a) * 3 + (((quad - a) & 3) - 1)) * 4 + rr) * 64 + lane] = v;
             }
         }
         __syncthreads();
@@ -337,7 +313,7 @@ __global__ __launch_bounds__(W4THREADS) void wino4_kernel(Wino4Desc d) {
         for (int rr = 0; rr < 4; rr++) {
             f32x4 v = own[rr];
 #pragma unroll
-            for (int s = 0; s < 3; s++) v += X(grp * 4 + quad)[(s * 4 + rr) * 64 + lane];
+            for (int s = 0; s < 3; s++) v += X[(((grp * 4 + quad) * 3 + s) * 4 + rr) * 64 + lane];
             const int m = mt * W4BM + grp * 32 + rr + 8 * ch + 4 * lk;
             const float sc_o = ob ? ob[m] : 1.0f;
             if (raw) {
@@ -407,6 +383,7 @@ extern "C" int g2s_wino4_supported(int B, int Cr, int M, int H, int W) {
     if (H % 4 || W % 4 || M % W4BM || Cr % W4KC) return 0;
     const int TW = W / 4;
     if (TW > W4BT || W4BT % TW) return 0;
+    if (((H / 4) * TW) % W4BT || Cr > W4MAXC) return 0;   // a block's 32 tiles lie in one image; its scale table
     if ((long)B * Cr * H * W >= (1l << 29) || (long)B * M * H * W >= (1l << 29)) return 0;
     return g2s_wino4_weights_floats(M, Cr) < ((size_t)1 << 29);
 }

@@ -92,26 +92,33 @@ except ImportError:
 
 
 def wino_choice(x, w, mode, transpose, fused):
-    """None: direct implicit GEMM; else the `splitk` argument of g2s_conv3x3_wino."""
+    """None: direct implicit GEMM; an int: the `splitk` argument of g2s_conv3x3_wino (F(2x2)); "w4:k": the F(4x4)
+    kernel with splitk = k."""
     B, Cr, H, W = x.shape
     if not (WINOGRAD and mode == PLAIN and w.shape[2] == 3 and w.shape[3] == 3 and not w.requires_grad
             and H >= 2 and W >= 2):
         return None
-    if WINO_FORCE is not None:
-        return None if WINO_FORCE == "direct" else int(WINO_FORCE)
     M = w.shape[1] if transpose else w.shape[0]
+
+    def checked(choice):   # "w4:k" only where the F(4x4) kernel takes the shape; else F(2x2), library partition
+        if isinstance(choice, str) and choice.startswith("w4"):
+            return choice if wino4_supported(B, Cr, M, H, W) else 0
+        return None if choice == "direct" else int(choice)
+
+    if WINO_FORCE is not None:
+        return checked(WINO_FORCE)
     hit = _WINO_TABLE.get((B, Cr, M, H, W, int(transpose), int(fused)))
     if hit is None:     # the row measured without / with the epilogue
         hit = _WINO_TABLE.get((B, Cr, M, H, W, int(transpose), 1 - int(fused)))
     if hit is not None:
-        return None if hit == "direct" else int(hit)
+        return checked(hit)
     # unmeasured signature: Winograd when there is enough work for the 64-channel x 64-tile
     # workgroups (>= 2 rounds of whole tiles, or stream-K runs of >= 32 K tiles)
     tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
     blocks = -(-tiles // 64) * -(-M // 64)
     if tiles < WINO_MIN_TILES or blocks * -(-Cr // 4) < 256 * 32 or M <= 32:   # M <= 32: the direct 32x128 tile
         return None
-    return 0
+    return "w4:0" if _wino4_default(B, Cr, M, H, W) else 0
 
 
 def wino_eligible(x, w, mode, H, W):
@@ -135,26 +142,23 @@ def wino_weights(w, transpose):
     return hit[1]
 
 
-# Winograd F(4x4, 3x3) (csrc/winograd4.hip) for the large maps: 1.78x fewer MFMA operations than F(2x2).
-# WINO4 = False keeps every Winograd layer on F(2x2); WINO4_FORCE (tests / tools): "on" = whenever the kernel
-# supports the shape, "off", or None = the built-in choice below.
+# Winograd F(4x4, 3x3) (csrc/winograd4.hip) for the large maps: 1.78x fewer MFMA operations than F(2x2).  A choice
+# "w4:k" (wino_choice / WINO_FORCE / the tuned table) sends the launch there with splitk = k (0: library choice);
+# WINO4 = False keeps every Winograd layer on F(2x2).
 WINO4 = True
-WINO4_FORCE = None
-WINO4_SPLITK = 0    # tests / tools: the kernel's splitk argument (0 = library choice)
-WINO4_MIN_BLOCKS = 128   # 64-channel x 32-tile workgroups below which F(2x2)'s stream-K partition fills the chip better
 _WINO4_U = {}
 
 
-def wino4_choice(B, Cr, M, H, W):
-    """True: this 3x3 stride-1 launch goes to the F(4x4, 3x3) kernel."""
-    if WINO4_FORCE == "off" or not (WINO4 or WINO4_FORCE == "on"):
+def wino4_supported(B, Cr, M, H, W):
+    return WINO4 and _lib.load().g2s_wino4_supported(B, Cr, M, H, W) == 1
+
+
+def _wino4_default(B, Cr, M, H, W):
+    """Unmeasured signature: F(4x4) when its 64-channel x 32-tile workgroups fill their rounds of 256 CUs."""
+    if not wino4_supported(B, Cr, M, H, W) or Cr < 64:
         return False
-    if _lib.load().g2s_wino4_supported(B, Cr, M, H, W) != 1:
-        return False
-    if WINO4_FORCE == "on":
-        return True
-    blocks = (M // 64) * -(-(B * (H // 4) * (W // 4)) // 32)
-    return blocks >= WINO4_MIN_BLOCKS and Cr >= 64
+    blocks = (M // 64) * (B * (H // 4) * (W // 4) // 32)
+    return blocks >= 192 and blocks / (-(-blocks // 256) * 256) >= 0.7
 
 
 def wino4_weights(w, transpose):
@@ -174,18 +178,18 @@ def wino4_weights(w, transpose):
 
 
 def _wino_launch(x, w, in_scale, out_scale, bias, transpose, act, alpha, gain, y, splitk=0, noise=None, noise_w=None):
-    """One stride-1 3x3 launch on a Winograd kernel: F(4x4) where wino4_choice says so, else F(2x2) with the
-    partition `splitk`.  noise / noise_w: the StyledConv tail (then bias and act = 1 are required)."""
+    """One stride-1 3x3 launch on a Winograd kernel: `splitk` is wino_choice's answer — "w4:k" = F(4x4), an int =
+    F(2x2) with that partition.  noise / noise_w: the StyledConv tail (then bias and act = 1 are required)."""
     B, Cr, H, W = x.shape
     M = y.shape[1]
     L = _lib.load()
     flop, nbytes = 2.0 * B * M * Cr * 9 * H * W, 4.0 * (x.numel() + w.numel() + y.numel())
-    if wino4_choice(B, Cr, M, H, W):
+    if isinstance(splitk, str):   # "w4:k"
         U = wino4_weights(w, transpose)
         with profiled(flop, nbytes, 2.0 * 36 * B * (H // 4) * (W // 4) * M * Cr):
             _lib.check(L.g2s_conv3x3_wino4(_lib.ptr(x), _lib.ptr(U), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                            _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(y), B, Cr, M, H, W,
-                                           int(act), float(alpha), float(gain), int(WINO4_SPLITK), *_lib.split_ws(),
+                                           int(act), float(alpha), float(gain), int(splitk[3:] or 0), *_lib.split_ws(),
                                            _lib.stream()))
         return y
     U = wino_weights(w, transpose)

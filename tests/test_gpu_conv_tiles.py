@@ -11,7 +11,8 @@ iteration (profiles/r01_c_bench_timed_region.txt).  Here each signature runs wit
 forward (in-scale = style, out-scale = demodulation) and transposed (data-gradient: in-scale =
 demodulation), against oracle.capi.modconv (stylegan2-pytorch/model.py:250-291 restated in C,
 double accumulation).  Tolerance: rtol 2e-4, atol 2e-5 * max(1, sqrt(K / 1152)) (fp32 MFMA sums of
-K = Cin * k^2 terms; the summation order is all that differs)."""
+K = Cin * k^2 terms; the summation order is all that differs); where the dispatcher picks the F(4x4,3x3) Winograd
+kernel: atol 1e-4 * max(1, sqrt(K / 1152)) (_check4: its transform constants amplify the rounding)."""
 import math
 
 import numpy as np
@@ -59,6 +60,17 @@ def _check(y, exp, K, what):
     np.testing.assert_allclose(got, exp, rtol=2e-4, atol=atol, err_msg=what)
 
 
+def _check_dispatched(y, exp, K, what, xd, wd, mode, transpose, fused):
+    """The dispatcher's own choice for this signature: the F(4x4) Winograd kernel carries its own tolerance
+    (_check4 below), every other kernel the one of the direct kernel."""
+    from gan2shape_amd import modconv as mc
+    choice = mc.wino_choice(xd, wd, mode, transpose, fused)
+    if isinstance(choice, str):
+        _check4(y, exp, K, f"{what} [{choice}]")
+    else:
+        _check(y, exp, K, f"{what} [{choice}]")
+
+
 # (B, Cin, Cout, H, k, mode): the generator's / discriminator's own layers at B = 8 (SURVEY §8a
 # layer table; D: stylegan2-pytorch/model.py:630-697 at size 128, cm = 1)
 SIGNATURES = [
@@ -95,7 +107,8 @@ def test_modconv_every_tile_vs_oracle(L, B, cin, cout, H, k, mode, transpose):
     K = (cout if transpose else cin) * k * k
     try:
         L.g2s_modconv_tune(-1, -1)
-        _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, "built-in choice (measured table: direct / Winograd)")
+        _check_dispatched(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K,
+                          "built-in choice (measured table: direct / Winograd)", xd, wd, mode, transpose, 0)
         with direct_kernel():
             _check(modconv_raw(xd, wd, sid, sod, mode, transpose), exp, K, "built-in direct choice")
             for tile in TILES:
@@ -127,7 +140,8 @@ def test_conv_bias_act_every_tile_vs_oracle(L, B, cin, cout, H, alpha, gain):
     # with the absolute tolerance only (|slope difference| * |pre| <= atol)
     xd, wd, bd = dev(x), dev(w), dev(b)
     try:
-        _check(conv_bias_act(xd, wd, bd, PLAIN, alpha, gain), exp, cin * 9, "built-in choice (measured table)")
+        _check_dispatched(conv_bias_act(xd, wd, bd, PLAIN, alpha, gain), exp, cin * 9, "built-in choice (measured table)",
+                          xd, wd, PLAIN, 0, 1)
         from gan2shape_amd import modconv as mc
         for force in (0, 1, 4, -256):   # Winograd with the fused / reduce-pass / deferred epilogue: library choice, whole tiles, split-K, stream-K
             mc.WINO_FORCE = force
@@ -216,6 +230,103 @@ def test_winograd_vs_oracle(L, B, cin, cout, H, W, transpose):
         _check(mc.modconv_raw(xd, wd, sid, sod, PLAIN, transpose), exp, cx * 9, "split-K 8, stored slices")
     finally:
         mc.WINOGRAD, mc.WINO_FORCE = saved
+
+
+# (B, Cin, Cout, H, W) for the F(4x4,3x3) kernel: whole 4x4 tiles, W / 4 divides 32, an image holds a multiple of 32 tiles
+WINO4_CASES = [
+    (8, 128, 128, 128, 128),   # G convs[9] / D conv1 at 128^2: 32 tiles = one tile row
+    (8, 256, 256, 64, 64),     # two tile rows per block
+    (8, 512, 512, 32, 32),     # four tile rows per block; library choice = 2 K slices
+    (9, 64, 128, 64, 64),      # VGG conv2_1 at B = 9 (data-gradient form: 128 -> 64)
+    (3, 68, 64, 32, 64),       # Cr a multiple of 4 only, non-square map
+    (2, 64, 192, 16, 32),      # the smallest image that holds 32 tiles; three channel blocks
+]
+
+
+def _check4(y, exp, K, what):
+    """F(4x4,3x3) in fp32: transform constants up to 8 and 1/24 amplify the rounding of the 36 products;
+    measured <= 1.5e-5 of max|y| on the workload's layers (profiles/r04_wino4_microbench.txt) against 7e-7 for
+    F(2x2): five times the direct kernel's atol."""
+    atol = 1e-4 * max(1.0, math.sqrt(K / 1152.0))
+    got = y.cpu().numpy()
+    assert got.shape == exp.shape, (what, got.shape, exp.shape)
+    np.testing.assert_allclose(got, exp, rtol=2e-4, atol=atol, err_msg=what)
+
+
+@pytest.mark.parametrize("transpose", [0, 1])
+@pytest.mark.parametrize("B,cin,cout,H,W", WINO4_CASES)
+def test_winograd4_vs_oracle(L, B, cin, cout, H, W, transpose):
+    """g2s_conv3x3_wino4 (transformed weights from g2s_wino4_weights) against the direct-convolution oracle:
+    forward and data-gradient form, whole tiles and 2 / 3 K slices through the workspace, with and without the
+    style / demodulation scales, without a workspace (falls back to whole tiles); shapes the kernel does not
+    take go to F(2x2)."""
+    from gan2shape_amd import lib, modconv as mc
+    rng = np.random.default_rng(B + cin + cout + H + W + transpose + 44)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+    cx, cy = (cout, cin) if transpose else (cin, cout)
+    xd_shape = (B, cx, H, W)
+    saved = (mc.WINOGRAD, mc.WINO_FORCE, mc.WINO4)
+    try:
+        mc.WINOGRAD, mc.WINO4, mc.WINO_FORCE = True, True, "w4:0"
+        if not mc.wino4_supported(B, cx, cy, H, W):
+            x0 = torch.zeros(xd_shape, device="cuda")
+            assert mc.wino_choice(x0, dev(w), PLAIN, transpose, 0) == 0    # F(2x2), library partition
+            return
+        x = rng.standard_normal(xd_shape).astype(np.float32)
+        s_in = (1 + 0.3 * rng.standard_normal((B, cx))).astype(np.float32)
+        s_out = None if transpose else (1 + 0.3 * rng.standard_normal((B, cy))).astype(np.float32)
+        exp = expected_modconv(x, w, s_in, s_out, PLAIN, transpose)
+        exp_plain = expected_modconv(x, w, None, None, PLAIN, transpose)
+        xd, wd, sid = dev(x), dev(w), dev(s_in)
+        sod = None if s_out is None else dev(s_out)
+        for sk in (0, 1, 2, 3):
+            mc.WINO_FORCE = f"w4:{sk}"
+            assert mc.wino_choice(xd, wd, PLAIN, transpose, 0) == f"w4:{sk}"
+            _check4(mc.modconv_raw(xd, wd, sid, sod, PLAIN, transpose), exp, cx * 9, f"F(4x4) splitk {sk}")
+        mc.WINO_FORCE = "w4:0"
+        _check4(mc.modconv_raw(xd, wd, None, None, PLAIN, transpose), exp_plain, cx * 9, "F(4x4), no scales")
+        real = lib.split_ws
+        lib.split_ws = lambda: (None, 0)       # no workspace: the K split is dropped, whole tiles
+        try:
+            mc.WINO_FORCE = "w4:3"
+            _check4(mc.modconv_raw(xd, wd, sid, sod, PLAIN, transpose), exp, cx * 9, "F(4x4) splitk 3, no workspace")
+        finally:
+            lib.split_ws = real
+        mc.WINO4 = False
+        assert mc.wino_choice(xd, wd, PLAIN, transpose, 0) == 0
+    finally:
+        mc.WINOGRAD, mc.WINO_FORCE, mc.WINO4 = saved
+
+
+@pytest.mark.parametrize("B,cin,cout,H", [(8, 128, 128, 128), (8, 512, 512, 32), (2, 64, 192, 32)])
+def test_winograd4_epilogues_vs_oracle(L, B, cin, cout, H):
+    """The two epilogues of g2s_conv3x3_wino4 on the workload's call paths: the StyledConv tail (noise + bias +
+    leaky-ReLU: modconv.modconv_nba_raw) and bias + leaky-ReLU without scales (conv_bias_act: D's conv1), whole
+    tiles and K slices (the reduce pass applies the tail there)."""
+    from gan2shape_amd import modconv as mc
+    from gan2shape_amd.modconv import conv_bias_act
+    rng = np.random.default_rng(B + cin + cout + H + 45)
+    x = rng.standard_normal((B, cin, H, H)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) / math.sqrt(cin * 9)).astype(np.float32)
+    s_in = (1 + 0.3 * rng.standard_normal((B, cin))).astype(np.float32)
+    s_out = (1 + 0.3 * rng.standard_normal((B, cout))).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    noise = rng.standard_normal((H, H)).astype(np.float32)
+    nw, alpha, gain = 0.37, 0.2, 2 ** 0.5
+    exp = _nba_expected(expected_modconv(x, w, s_in, s_out, PLAIN, 0), bias, noise, nw, alpha, gain)
+    pre = expected_modconv(x, w, None, None, PLAIN, 0) + bias[None, :, None, None]
+    exp_ba = (np.where(pre > 0, pre, pre * alpha) * gain).astype(np.float32)
+    args = (dev(x), dev(w), dev(s_in), dev(s_out), dev(bias), dev(noise).view(1, 1, H, H), dev(np.array([nw], np.float32)), alpha, gain)
+    saved = (mc.WINOGRAD, mc.WINO_FORCE, mc.WINO4)
+    try:
+        mc.WINOGRAD, mc.WINO4 = True, True
+        assert mc.wino4_supported(B, cin, cout, H, H)
+        for sk in (1, 2):
+            mc.WINO_FORCE = f"w4:{sk}"
+            _check4(mc.modconv_nba_raw(*args), exp, cin * 9, f"F(4x4) StyledConv tail, splitk {sk}")
+            _check4(conv_bias_act(dev(x), dev(w), dev(bias), PLAIN, alpha, gain), exp_ba, cin * 9, f"F(4x4) bias + act, splitk {sk}")
+    finally:
+        mc.WINOGRAD, mc.WINO_FORCE, mc.WINO4 = saved
 
 
 def test_winograd_weights_follow_the_tensor_version(L):
@@ -330,7 +441,7 @@ def test_styledconv_tail_in_the_epilogue_vs_oracle(L, B, cin, cout, H):
     saved = (mc.WINOGRAD, mc.WINO_FORCE)
     try:
         L.g2s_modconv_tune(-1, -1)
-        _check(mc.modconv_nba_raw(*args), exp, K, "built-in choice")
+        _check_dispatched(mc.modconv_nba_raw(*args), exp, K, "built-in choice", args[0], args[1], PLAIN, 0, 1)
         if H >= 8:
             mc.WINOGRAD = True
             for sk in (0, 1, 3, -7, -256):

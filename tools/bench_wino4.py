@@ -56,17 +56,15 @@ for B, cin, cout, H in SIGS:
     def run():
         return mc.modconv_raw(x, w, s, d, mc.PLAIN, 0)
 
-    mc.WINO4_FORCE = "off"
     mc.WINO_FORCE = "direct"
     t_d, e_d = timeit(run), err(run())
     mc.WINO_FORCE = 0
     t_2, e_2 = timeit(run), err(run())
     row = f"{str((B, cin, cout, H)):24s} {t_d:8.1f} {t_2:8.1f} {flop / t_2 / 1e6:6.1f} | "
-    mc.WINO4_FORCE = "on"
     e_4 = float("nan")
     for sk in splits:
-        mc.WINO4_SPLITK = sk
-        if not mc.wino4_choice(B, cin, cout, H, H):
+        mc.WINO_FORCE = f"w4:{sk}"
+        if not mc.wino4_supported(B, cin, cout, H, H):
             row += f"{'unsupported':>32s} | "
             continue
         t_4, e_4 = timeit(run), err(run())

@@ -15,8 +15,7 @@ x = torch.randn(B, cin, H, H, device="cuda")
 w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
 s = torch.rand(B, cin, device="cuda") + 0.5
 d = torch.rand(B, cout, device="cuda") + 0.5
-mc.WINO_FORCE = 0
-mc.WINO4_FORCE = "on" if kind == "f4" else "off"
+mc.WINO_FORCE = "w4:0" if kind == "f4" else 0
 for _ in range(N):
     mc.modconv_raw(x, w, s, d, mc.PLAIN, 0)
 torch.cuda.synchronize()
