@@ -459,7 +459,8 @@ def self_launch(n_ranks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 40 = two cycles of the 7:7:6 mix; car128_joint: 53 = one cycle of 13:22:18)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n-proj", type=int, default=8)
     ap.add_argument("--workload", default="face128_n8", choices=sorted(WORKLOADS),
@@ -480,8 +481,12 @@ def main():
     joint = bool(WORKLOADS[args.workload].get("joint"))
     if joint:
         PATTERN = list(JOINT_PATTERN)
+        if args.steps is None:
+            args.steps = len(JOINT_PATTERN)   # a whole cycle: the timed region starts at step 1 of the mix
     if args.only:
         PATTERN = [args.only]
+    if args.steps is None:
+        args.steps = 40
     import gan2shape_amd  # noqa: F401
     from gan2shape_amd import sharding
     # RCCL ("nccl") on a multi-GPU node; G2S_DIST_BACKEND=gloo rehearses the N>1 path on one GPU
@@ -600,12 +605,12 @@ def main():
         kind_ms = {k: (v if not isinstance(v, list) else None) for k, v in runner.kind_ms.items()}
         times = [p[1].elapsed_time(p[2]) for p in prof]
         flops = sum(p[0] for p in prof)            # algorithmic: direct-convolution FLOP
-        mfma = sum(p[4] for p in prof)             # what the matrix cores execute (Winograd: 16 / 36 of it)
+        mfma = sum(p[4] for p in prof)             # what the matrix cores execute (Winograd F(2x2): 16 / 36 of it, F(4x4): 36 / 144)
         ms = sum(times)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         executed = mfma / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         per_kernel = {}
-        for name in ("direct", "winograd"):
+        for name in ("direct", "winograd", "winograd4"):
             sel = [(p, t) for p, t in zip(prof, times) if p[5] == name]
             tk = sum(t for _, t in sel)
             if sel and tk > 0:
@@ -635,14 +640,17 @@ def main():
             with open(pmc[-1]) as f:
                 traffic = json.load(f)["traffic_bytes_per_launch"]
             traffic_src = os.path.relpath(pmc[-1], ROOT)
-        # `frac` is the fraction of the fp32-MFMA peak the matrix cores actually EXECUTE (a Winograd
-        # launch does 16 multiplications per 4 outputs where the direct convolution does 36): the only
-        # figure that cannot exceed 1.  The direct-convolution (algorithmic) rate is kept beside it.
+        # `frac` is the fraction of the fp32-MFMA peak the matrix cores actually EXECUTE (a Winograd F(2x2)
+        # launch does 16 multiplications per 4 outputs where the direct convolution does 36, an F(4x4) launch
+        # 36 per 16 instead of 144): the only figure that cannot exceed 1.  The direct-convolution
+        # (algorithmic) rate is kept beside it.  Moving a layer from F(2x2) to F(4x4) LOWERS `frac` (1.78x
+        # fewer FLOP for the same outputs, 1.2x less time) while the algorithmic rate and the step rate rise.
         roofline = {"bound": "mfma", "achieved": executed, "peak": F32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": executed / F32_MFMA_PEAK_TFLOPS,
                     "achieved_is": "FLOP the matrix cores execute / HIP-event time over every launch of the fp32-MFMA "
                                    "convolution kernels in one 20-step cycle (direct kernel: the algorithmic FLOP of the "
-                                   "convolution; Winograd kernel: 16/36 of it)",
+                                   "convolution; Winograd F(2x2): 16/36 of it; Winograd F(4x4), round 4: 36/144 of it — which is why this "
+                                   "fraction fell from round 3 while the algorithmic rate and iters/s rose)",
                     "algorithmic": {"achieved": achieved, "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                                     "is": "direct-convolution FLOP of the same launches / the same time (Winograd "
                                           "launches alone exceed 1.0 on this scale: not a roofline, a speed-up)"},
@@ -662,7 +670,8 @@ def main():
                     "algorithmic_bytes_per_launch": (sum(p[3] for p in prof) / len(prof)) if prof else None,
                     "kernel": "the fp32-MFMA convolution kernels g2s::modconv_kernel (direct implicit GEMM; with "
                               "g2s::conv_bwd_kernel, the same body next to the weight-gradient GEMM of a layer) + "
-                              "g2s::wino_kernel (Winograd F(2x2,3x3)): every launch of the 20-step cycle — "
+                              "g2s::wino_kernel (Winograd F(2x2,3x3)) + g2s::wino4_kernel (Winograd F(4x4,3x3)): every launch of "
+                              "the 20-step cycle — "
                               "generator, discriminator, VGG and the small trained nets",
                     "per_kernel": per_kernel,
                     "large_launches": _large(prof),

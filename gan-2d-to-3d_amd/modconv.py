@@ -12,6 +12,8 @@ Gradients (all on the GPU, no CPU path):
          GAN2Shape/model.py:26-37 keeps G in eval mode and no optimiser owns it) via torch's conv
          weight-gradient.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -29,12 +31,13 @@ PROFILE = None
 class profiled:
     """with profiled(flop, nbytes[, mfma_flop]): <one launch of the MFMA convolution kernels>.
     `flop` is the ALGORITHMIC count of the direct convolution; `mfma_flop` what the matrix cores
-    execute (smaller for the Winograd kernel: 16 multiplications per 4 outputs instead of 36)."""
+    execute (smaller for the Winograd kernels: 16 multiplications per 4 outputs (F(2x2)) or 36 per 16 (F(4x4))
+    instead of 36 per 4 / 144 per 16)."""
 
-    def __init__(self, flop, nbytes, mfma_flop=None):
+    def __init__(self, flop, nbytes, mfma_flop=None, kernel=None):
         self.rec = PROFILE
         self.flop, self.nbytes = flop, nbytes
-        self.kernel = "direct" if mfma_flop is None else "winograd"
+        self.kernel = kernel or ("direct" if mfma_flop is None else "winograd")
         self.mfma_flop = flop if mfma_flop is None else mfma_flop
 
     def __enter__(self):
@@ -118,7 +121,7 @@ def wino_choice(x, w, mode, transpose, fused):
     blocks = -(-tiles // 64) * -(-M // 64)
     if tiles < WINO_MIN_TILES or blocks * -(-Cr // 4) < 256 * 32 or M <= 32:   # M <= 32: the direct 32x128 tile
         return None
-    return "w4:0" if _wino4_default(B, Cr, M, H, W) else 0
+    return 0   # F(4x4) only where the table measured it ahead: on unmeasured signatures it lost as often as it won
 
 
 def wino_eligible(x, w, mode, H, W):
@@ -143,22 +146,15 @@ def wino_weights(w, transpose):
 
 
 # Winograd F(4x4, 3x3) (csrc/winograd4.hip) for the large maps: 1.78x fewer MFMA operations than F(2x2).  A choice
-# "w4:k" (wino_choice / WINO_FORCE / the tuned table) sends the launch there with splitk = k (0: library choice);
-# WINO4 = False keeps every Winograd layer on F(2x2).
-WINO4 = True
+# "w4:k" (WINO_FORCE / the tuned table: wino_choice) sends the launch there with splitk = k (0: library choice);
+# unmeasured signatures stay on F(2x2) (car128_joint, whose batch sizes are not in the table, ran 8 % slower with
+# a fill-based default).  WINO4 = False keeps every Winograd layer on F(2x2).
+WINO4 = os.environ.get("G2S_WINO4", "1") != "0"   # G2S_WINO4=0: measurement runs without the F(4x4) kernel
 _WINO4_U = {}
 
 
 def wino4_supported(B, Cr, M, H, W):
     return WINO4 and _lib.load().g2s_wino4_supported(B, Cr, M, H, W) == 1
-
-
-def _wino4_default(B, Cr, M, H, W):
-    """Unmeasured signature: F(4x4) when its 64-channel x 32-tile workgroups fill their rounds of 256 CUs."""
-    if not wino4_supported(B, Cr, M, H, W) or Cr < 64:
-        return False
-    blocks = (M // 64) * (B * (H // 4) * (W // 4) // 32)
-    return blocks >= 192 and blocks / (-(-blocks // 256) * 256) >= 0.7
 
 
 def wino4_weights(w, transpose):
@@ -186,7 +182,7 @@ def _wino_launch(x, w, in_scale, out_scale, bias, transpose, act, alpha, gain, y
     flop, nbytes = 2.0 * B * M * Cr * 9 * H * W, 4.0 * (x.numel() + w.numel() + y.numel())
     if isinstance(splitk, str):   # "w4:k"
         U = wino4_weights(w, transpose)
-        with profiled(flop, nbytes, 2.0 * 36 * B * (H // 4) * (W // 4) * M * Cr):
+        with profiled(flop, nbytes, 2.0 * 36 * B * (H // 4) * (W // 4) * M * Cr, "winograd4"):
             _lib.check(L.g2s_conv3x3_wino4(_lib.ptr(x), _lib.ptr(U), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                            _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(y), B, Cr, M, H, W,
                                            int(act), float(alpha), float(gain), int(splitk[3:] or 0), *_lib.split_ws(),

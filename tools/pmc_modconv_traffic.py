@@ -7,7 +7,7 @@ the launches after the marker kernel (the 20-step 7:7:6 cycle) are counted.
 python tools/pmc_modconv_traffic.py fetch.csv write.csv out.json"""
 import csv, json, sys
 
-KERNELS = {"direct": ("modconv_kernel", "conv_bwd_kernel"), "winograd": ("wino_kernel",)}
+KERNELS = {"direct": ("modconv_kernel", "conv_bwd_kernel"), "winograd": ("wino_kernel", "wino4_kernel")}
 
 
 def load(path, counter):
@@ -32,7 +32,7 @@ for name, pat in KERNELS.items():
     wk, _ = mean(wr, pat)
     per[name] = {"launches": nk, "fetch_bytes_per_launch": 2 * fk * 1024, "write_bytes_per_launch": wk * 1024,
                  "traffic_bytes_per_launch": 2 * fk * 1024 + wk * 1024}
-out = {"kernel": "g2s::modconv_kernel + g2s::conv_bwd_kernel + g2s::wino_kernel", "launches_fetch_pass": nf, "launches_write_pass": nw,
+out = {"kernel": "g2s::modconv_kernel + g2s::conv_bwd_kernel + g2s::wino_kernel + g2s::wino4_kernel", "launches_fetch_pass": nf, "launches_write_pass": nw,
        "fetch_bytes_per_launch": 2 * f * 1024, "write_bytes_per_launch": w * 1024,
        "traffic_bytes_per_launch": 2 * f * 1024 + w * 1024, "per_kernel": per,
        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE x1",

@@ -17,7 +17,7 @@ assert len(marks) >= 2, f"need two marker kernels, found {len(marks)}"
 rows = rows[marks[0] + 1:marks[1]]
 span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e6
 cats = collections.OrderedDict([
-    ("g2s modconv (MFMA implicit GEMM)", ("modconv_kernel", "conv_bwd_kernel")), ("g2s winograd (MFMA F(2x2,3x3))", ("wino_kernel",)), ("g2s upfirdn2d", ("upfirdn2d",)),
+    ("g2s modconv (MFMA implicit GEMM)", ("modconv_kernel", "conv_bwd_kernel")), ("g2s winograd F(2x2,3x3) (MFMA)", ("wino_kernel",)), ("g2s winograd F(4x4,3x3) (MFMA)", ("wino4_kernel",)), ("g2s upfirdn2d", ("upfirdn2d",)),
     ("g2s bias/act", ("fba_", "noise_bias")), ("g2s raster", ("raster_",)),
     ("g2s geometry/shading/lpips/rowops", ("g2s::",)),
     ("MIOpen conv (winograd/igemm/gemm)", ("miopenSp3", "igemm_", "Cijk_", "gemm", "Im2d2Col", "Col2Im", "naive_conv", "MIOpen", "conv")),
@@ -50,12 +50,15 @@ print("top kernels (per iteration):")
 for n, v in sorted(per.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"  {v[1] / iters / 1e3:7.3f} ms {100 * v[1] / T:5.1f}% n={v[0] / iters:6.1f} avg={v[1] / v[0]:8.1f}us  {n[:120]}")
 if len(sys.argv) > 4:
-    direct, wino = tot["g2s modconv (MFMA implicit GEMM)"], tot["g2s winograd (MFMA F(2x2,3x3))"]
+    direct, wino2, wino4 = (tot["g2s modconv (MFMA implicit GEMM)"], tot["g2s winograd F(2x2,3x3) (MFMA)"],
+                            tot["g2s winograd F(4x4,3x3) (MFMA)"])
+    wino = wino2 + wino4
     with open(sys.argv[4], "w") as f:
         json.dump({"what": "rocprofv3 --kernel-trace durations inside the graph-replayed timed region of bench.py (G2S_BENCH_MARK=1), per iteration",
                    "iterations": iters, "launches_per_iteration": len(rows) / iters, "kernel_ms_per_iteration": T / iters / 1e3,
                    "wall_ms_per_iteration": span / iters,
                    "conv_ms_per_iteration": {"direct": direct / iters / 1e3, "winograd": wino / iters / 1e3,
+                                             "winograd_f2x2": wino2 / iters / 1e3, "winograd_f4x4": wino4 / iters / 1e3,
                                              "total": (direct + wino) / iters / 1e3},
                    "conv_launches_per_iteration": {"direct": cnt["g2s modconv (MFMA implicit GEMM)"] / iters,
-                                                   "winograd": cnt["g2s winograd (MFMA F(2x2,3x3))"] / iters}}, f, indent=1)
+                                                   "winograd": (cnt["g2s winograd F(2x2,3x3) (MFMA)"] + cnt["g2s winograd F(4x4,3x3) (MFMA)"]) / iters}}, f, indent=1)
