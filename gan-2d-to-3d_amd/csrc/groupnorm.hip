@@ -1,5 +1,6 @@
-// groupnorm.hip — GroupNorm + (leaky-)ReLU of the depth / albedo nets as two launches per direction,
-// behind g2s_groupnorm_act_fwd / _bwd (include/g2s.h).
+// groupnorm.hip — GroupNorm + (leaky-)ReLU of the depth / albedo nets, behind g2s_groupnorm_act_fwd / _bwd
+// (include/g2s.h): ONE launch per direction when a group fits the registers of one workgroup (round 4: every
+// layer of the nets at 128^2), two launches per direction otherwise.
 //
 // The EncoderDecoder nets (GAN2Shape/networks.py:79-141) put nn.GroupNorm + nn.ReLU / nn.LeakyReLU
 // after 11 of their convolutions and run at batch 1: PyTorch spends 4 launches forward and 5
@@ -198,6 +199,161 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_apply(GnBwdParams p) {
     reinterpret_cast<float4 *>(p.dx)[i4] = o;
 }
 
+// ---- one launch per direction for the groups that fit the registers of ONE workgroup (n <= 65536 elements:
+// every GroupNorm of the depth / albedo nets at 128^2, whose pair pass runs them at B = 1 with 16 .. 64 groups
+// of 1024 .. 65536 elements).  1024 threads, up to 16 float4 per thread; the sums keep a fixed order.
+constexpr int GNF_THREADS = 1024;
+constexpr int GNF_MAX4 = 16;                       // float4 per thread
+constexpr int GNF_MAX_N = GNF_THREADS * GNF_MAX4 * 4;
+
+// sum over the 1024 threads; every thread gets the result (sm: 16 floats)
+__device__ __forceinline__ float block_sum16(float v, float *sm) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; w++) t += sm[w];
+    return t;
+}
+
+// forward: exact two-pass moments of the whole group in registers, then y = act((x - mean) * rstd * gamma + beta)
+__global__ __launch_bounds__(GNF_THREADS) void gn_fwd_fused(GnParams p) {
+    __shared__ float sm[16];
+    const int bg = blockIdx.x, b = bg / p.G, g = bg % p.G;
+    const int cpg = p.C / p.G, n4 = p.n >> 2, hw4 = p.HW >> 2;
+    const float4 *x4 = reinterpret_cast<const float4 *>(p.x + (size_t)bg * p.n);
+    float4 v[GNF_MAX4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < GNF_MAX4; e++) {
+        const int i = e * GNF_THREADS + threadIdx.x;
+        v[e] = i < n4 ? x4[i] : make_float4(0, 0, 0, 0);
+        sum += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+    }
+    const float mean = block_sum16(sum, sm) / (float)p.n;
+    float m2 = 0.0f;
+#pragma unroll
+    for (int e = 0; e < GNF_MAX4; e++) {
+        if (e * GNF_THREADS + threadIdx.x < n4) {
+            const float a = v[e].x - mean, bb = v[e].y - mean, c = v[e].z - mean, dd = v[e].w - mean;
+            m2 += (a * a + bb * bb) + (c * c + dd * dd);
+        }
+    }
+    const float rstd = rsqrtf(block_sum16(m2, sm) / (float)p.n + p.eps);
+    if (threadIdx.x == 0) {
+        p.mean[bg] = mean;
+        p.rstd[bg] = rstd;
+    }
+    float4 *y4 = reinterpret_cast<float4 *>(p.y + (size_t)bg * p.n);
+#pragma unroll
+    for (int e = 0; e < GNF_MAX4; e++) {
+        const int i = e * GNF_THREADS + threadIdx.x;
+        if (i >= n4) continue;
+        const int c = g * cpg + i / hw4;
+        const float ga = p.gamma[c] * rstd, be = p.beta[c] - mean * ga;
+        float4 o = v[e];
+        o.x = o.x * ga + be;
+        o.y = o.y * ga + be;
+        o.z = o.z * ga + be;
+        o.w = o.w * ga + be;
+        if (p.act) {
+            o.x = o.x > 0.0f ? o.x : o.x * p.alpha;
+            o.y = o.y > 0.0f ? o.y : o.y * p.alpha;
+            o.z = o.z > 0.0f ? o.z : o.z * p.alpha;
+            o.w = o.w > 0.0f ? o.w : o.w * p.alpha;
+        }
+        y4[i] = o;
+    }
+    (void)b;
+}
+
+// backward at B = 1 (a channel's parameter gradient is its own (s1, s2)): H*W a multiple of 256, so the 256
+// elements a wave reads per pass lie in ONE channel; the per-(pass, wave) partial sums meet per channel in a
+// fixed order.  Two sweeps over gy, y, x (the second one hits L2: a group is at most 3 x 64 KB).
+constexpr int GNB_MAX_N = 16384;
+constexpr int GNB_MAX_PASSES = GNB_MAX_N / 4 / GNF_THREADS;   // 4
+
+__global__ __launch_bounds__(GNF_THREADS) void gn_bwd_fused(GnBwdParams p) {
+    __shared__ float part[GNB_MAX_PASSES * 16 * 2];
+    __shared__ float chan[16 * 2];      // (s1, s2 * rstd) per channel of the group (<= 16: one wave each)
+    __shared__ float grp[2];
+    const int g = blockIdx.x;           // B = 1
+    const int cpg = p.C / p.G, n4 = p.n >> 2, hw4 = p.HW >> 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float mean = p.mean[g], rstd = p.rstd[g];
+    const size_t off = (size_t)g * p.n;
+    const float4 *gy4 = reinterpret_cast<const float4 *>(p.gy + off);
+    const float4 *y4 = reinterpret_cast<const float4 *>(p.y + off);
+    const float4 *x4 = reinterpret_cast<const float4 *>(p.x + off);
+    const int passes = (n4 + GNF_THREADS - 1) / GNF_THREADS;
+    for (int e = 0; e < passes; e++) {
+        const int i = e * GNF_THREADS + threadIdx.x;
+        float s1 = 0.0f, s2 = 0.0f;
+        if (i < n4) {
+            const float4 gg = gy4[i], yy = y4[i], xx = x4[i];
+            const float g0 = act_grad(gg.x, yy.x, p.act, p.alpha), g1 = act_grad(gg.y, yy.y, p.act, p.alpha);
+            const float g2 = act_grad(gg.z, yy.z, p.act, p.alpha), g3 = act_grad(gg.w, yy.w, p.act, p.alpha);
+            s1 = (g0 + g1) + (g2 + g3);
+            s2 = (g0 * (xx.x - mean) + g1 * (xx.y - mean)) + (g2 * (xx.z - mean) + g3 * (xx.w - mean));
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+            part[(e * 16 + wave) * 2] = s1;
+            part[(e * 16 + wave) * 2 + 1] = s2;
+        }
+    }
+    __syncthreads();
+    // channel k of the group = wave k: its (pass, wave) entries are the contiguous range [k L, (k + 1) L),
+    // L = HW / 256; lane j adds entries j, j + 64, .. and the wave reduces: a fixed summation tree
+    if (wave < cpg) {
+        const int L = hw4 >> 6;
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int j = lane; j < L; j += 64) {
+            s1 += part[(wave * L + j) * 2];
+            s2 += part[(wave * L + j) * 2 + 1];
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2) * rstd;
+        if (lane == 0) {
+            chan[2 * wave] = s1;
+            chan[2 * wave + 1] = s2;
+            p.dbeta[g * cpg + wave] = s1;
+            p.dgamma[g * cpg + wave] = s2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ds = 0.0f, db = 0.0f;
+        for (int k = 0; k < cpg; k++) {
+            const float ga = p.gamma[g * cpg + k];
+            db += ga * chan[2 * k];
+            ds += ga * chan[2 * k + 1];
+        }
+        grp[0] = ds;
+        grp[1] = db;
+    }
+    __syncthreads();
+    const float inv_n = 1.0f / (float)p.n;
+    const float c2 = -grp[0] * inv_n * rstd * rstd;   // coefficient of (x - mean)
+    const float c3 = -grp[1] * inv_n * rstd;
+    float4 *dx4 = reinterpret_cast<float4 *>(p.dx + off);
+    for (int e = 0; e < passes; e++) {
+        const int i = e * GNF_THREADS + threadIdx.x;
+        if (i >= n4) continue;
+        const float ga = p.gamma[g * cpg + i / hw4] * rstd;
+        const float4 gg = gy4[i], yy = y4[i], xx = x4[i];
+        float4 o;
+        o.x = act_grad(gg.x, yy.x, p.act, p.alpha) * ga + ((xx.x - mean) * c2 + c3);
+        o.y = act_grad(gg.y, yy.y, p.act, p.alpha) * ga + ((xx.y - mean) * c2 + c3);
+        o.z = act_grad(gg.z, yy.z, p.act, p.alpha) * ga + ((xx.z - mean) * c2 + c3);
+        o.w = act_grad(gg.w, yy.w, p.act, p.alpha) * ga + ((xx.w - mean) * c2 + c3);
+        dx4[i] = o;
+    }
+}
+
 static int gn_check(int B, int C, int HW, int G) {
     G2S_REQUIRE(B > 0 && C > 0 && HW > 0 && G > 0, "sizes must be positive");
     G2S_REQUIRE(C % G == 0, "channels %d not divisible by groups %d", C, G);
@@ -243,6 +399,10 @@ extern "C" int g2s_groupnorm_act_fwd(const float *x, const float *gamma, const f
     p.act = act;
     p.alpha = alpha;
     hipStream_t st = as_stream(stream);
+    if (p.n <= GNF_MAX_N) {   // the whole group in one workgroup's registers: one launch
+        gn_fwd_fused<<<B * G, GNF_THREADS, 0, st>>>(p);
+        return check_launch("g2s_groupnorm_act_fwd");
+    }
     gn_stats<<<dim3(p.S, B * G), GN_THREADS, 0, st>>>(p);
     gn_apply<<<cdiv((long)B * C * HW / 4, GN_THREADS), GN_THREADS, 0, st>>>(p);
     return check_launch("g2s_groupnorm_act_fwd");
@@ -276,6 +436,12 @@ extern "C" int g2s_groupnorm_act_bwd(const float *gy, const float *y, const floa
     p.act = act;
     p.alpha = alpha;
     hipStream_t st = as_stream(stream);
+    // one launch (the nets' pair passes) while a group is small enough for ONE CU to stream gy, y, x twice:
+    // the two 65536-element layers stay on the two-launch path (16 workgroups would each move 1.8 MB)
+    if (B == 1 && p.n <= GNB_MAX_N && HW % 256 == 0 && C / G <= 16) {
+        gn_bwd_fused<<<G, GNF_THREADS, 0, st>>>(p);
+        return check_launch("g2s_groupnorm_act_bwd");
+    }
     gn_bwd_sums<<<B * C, GN_THREADS, 0, st>>>(p);
     gn_bwd_apply<<<cdiv((long)B * C * HW / 4, GN_THREADS), GN_THREADS, 0, st>>>(p);
     return check_launch("g2s_groupnorm_act_bwd");
