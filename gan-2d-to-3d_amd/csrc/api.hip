@@ -14,7 +14,15 @@ int fail(int code, const char *fmt, ...) {
 }
 static std::atomic<int> g_deterministic{0};
 bool deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
+static thread_local int t_precleared = 0;
+bool precleared() { return t_precleared != 0; }
 }  // namespace g2s
+
+extern "C" int g2s_set_precleared(int on) {
+    const int prev = g2s::t_precleared;
+    g2s::t_precleared = on ? 1 : 0;
+    return prev;
+}
 
 extern "C" int g2s_set_deterministic(int on) {
     g2s::g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed);

@@ -13,6 +13,10 @@ int fail(int code, const char *fmt, ...);
 // g2s_set_deterministic (api.hip): launches choose partitions whose fp32 sums have a fixed order.
 bool deterministic();
 
+// g2s_set_precleared (api.hip, per thread): the caller guarantees that the accumulators a function would clear
+// itself (small gradient sums, fixed-point workspaces, scatter targets) are already zero: their memsets are skipped.
+bool precleared();
+
 inline hipStream_t as_stream(g2s_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Checks the launch (not the execution: no synchronisation inside the library).

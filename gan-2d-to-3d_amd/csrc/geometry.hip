@@ -462,7 +462,7 @@ extern "C" int g2s_warp_verts_bwd(const float *depth, const float *rays, const f
                                   float *gRt, int B, int P, g2s_stream_t stream) {
     G2S_REQUIRE(depth && rays && R && gverts && gdepth && B > 0 && P > 0 && B <= 65535, "bad argument");
     hipStream_t st = as_stream(stream);
-    if (gRt && hipMemsetAsync(gRt, 0, (size_t)B * 12 * sizeof(float), st) != hipSuccess)
+    if (gRt && !precleared() && hipMemsetAsync(gRt, 0, (size_t)B * 12 * sizeof(float), st) != hipSuccess)
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
     warp_verts_bwd<<<dim3(deterministic() ? 1 : cdiv(P, 256), B), 256, 0, st>>>(depth, rays, R, gverts, rot_center_depth, gdepth, gRt, P, gRt != nullptr);
     return check_launch("g2s_warp_verts_bwd");
@@ -483,7 +483,7 @@ extern "C" int g2s_inv_warp_grid_bwd(const float *depth, const float *rays, cons
                                      int W, g2s_stream_t stream) {
     G2S_REQUIRE(depth && rays && R && t && K && ggrid && gdepth && B > 0 && H > 1 && W > 1 && B <= 65535, "bad argument");
     hipStream_t st = as_stream(stream);
-    if (gRt && hipMemsetAsync(gRt, 0, (size_t)B * 12 * sizeof(float), st) != hipSuccess)
+    if (gRt && !precleared() && hipMemsetAsync(gRt, 0, (size_t)B * 12 * sizeof(float), st) != hipSuccess)
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
     inv_warp_grid_bwd<<<dim3(deterministic() ? 1 : cdiv(H * W, 256), B), 256, 0, st>>>(
         depth, rays, R, t, rot_center_depth, make_intr(K, H, W), ggrid, gdepth, gRt, H * W, gRt != nullptr);
@@ -501,7 +501,7 @@ extern "C" int g2s_smooth_loss_fwd(const float *p, float *loss, int N, int H, in
     float wxx, wxy, wyy;
     smooth_weights(N, H, W, wxx, wxy, wyy);
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
+    if (!precleared() && hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
     smooth_loss_fwd<<<deterministic() ? dim3(1, 1, 1) : dim3(cdiv(W, 32), cdiv(H, 8), N), 256, 0, st>>>(p, loss, N, H, W, wxx, wxy, wyy);
     return check_launch("g2s_smooth_loss_fwd");
 }
@@ -546,7 +546,7 @@ extern "C" int g2s_shading_bwd(const float *normal, const float *light, const fl
                 "bad argument");
     G2S_REQUIRE((Bn == 1 || Bn == B) && (Ba == 1 || Ba == B), "normal / albedo batch must be 1 or B");
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(glight, 0, (size_t)B * 4 * sizeof(float), st) != hipSuccess)
+    if (!precleared() && hipMemsetAsync(glight, 0, (size_t)B * 4 * sizeof(float), st) != hipSuccess)
         return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
     shading_bwd<<<dim3(deterministic() ? 1 : cdiv(P, 256), B), 256, 0, st>>>(normal, light, albedo, gdiffuse, gtexture, gnormal, galbedo, glight, P, Bn, Ba);
     return check_launch("g2s_shading_bwd");
@@ -565,7 +565,7 @@ extern "C" int g2s_depth_head_bwd(const float *raw, const float *mean, const flo
                                   g2s_stream_t stream) {
     G2S_REQUIRE(raw && mean && g && g_raw && gsum && n > 0 && W >= 4 && n % W == 0, "bad argument");
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(gsum, 0, sizeof(float), st) != hipSuccess) return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
+    if (!precleared() && hipMemsetAsync(gsum, 0, sizeof(float), st) != hipSuccess) return fail(G2S_ERR_LAUNCH, "hipMemsetAsync failed");
     const int blocks = deterministic() ? 1 : (int)std::min<long>(cdiv((long)n, 256), 1024);
     depth_head_bwd<<<blocks, 256, 0, st>>>(raw, mean, g, g_raw, gsum, (long)n, DepthHead{lo, hi, border_depth, W, clamp_border});
     sub_mean_kernel<<<cdiv((long)n, 256), 256, 0, st>>>(g_raw, gsum, (long)n);

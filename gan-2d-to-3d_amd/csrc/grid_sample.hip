@@ -168,12 +168,12 @@ extern "C" int g2s_grid_sample_bwd(const float *gy, const float *x, const float 
                         "(g2s_grid_sample_bwd_workspace_bytes = %zu bytes, got %zu)",
                         g2s_grid_sample_bwd_workspace_bytes(B, C, IH, IW), workspace ? workspace_bytes : (size_t)0);
         long long *fix = reinterpret_cast<long long *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-        if (hipMemsetAsync(fix, 0, n * sizeof(long long), st) != hipSuccess)
+        if (!precleared() && hipMemsetAsync(fix, 0, n * sizeof(long long), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
         grid_sample_bwd<true><<<g, 256, 0, st>>>(gy, x, grid, gx, fix, ggrid, d, clamp, lo, hi, 1);
         fixed_to_float<<<cdiv((long)n, 256), 256, 0, st>>>(fix, gx, (long)n);
     } else {
-        if (gx && hipMemsetAsync(gx, 0, n * sizeof(float), st) != hipSuccess)
+        if (gx && !precleared() && hipMemsetAsync(gx, 0, n * sizeof(float), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(gx) failed");
         grid_sample_bwd<false><<<g, 256, 0, st>>>(gy, x, grid, gx, nullptr, ggrid, d, clamp, lo, hi, gx != nullptr);
     }

@@ -740,11 +740,11 @@ extern "C" int g2s_raster_depth_bwd_ex(const float *verts, const int32_t *faces,
                         "(g2s_raster_bwd_workspace_bytes = %zu bytes, got %zu)",
                         g2s_raster_bwd_workspace_bytes(B, n_verts), workspace ? workspace_bytes : (size_t)0);
         p.gfix = reinterpret_cast<long long *>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-        if (hipMemsetAsync(p.gfix, 0, (size_t)B * n_verts * 3 * sizeof(long long), st) != hipSuccess)
+        if (!precleared() && hipMemsetAsync(p.gfix, 0, (size_t)B * n_verts * 3 * sizeof(long long), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(workspace) failed");
         raster_bwd_samples<long long><<<dim3(cdiv(bw_tiles, 4), B), 256, 0, st>>>(p);
     } else {
-        if (hipMemsetAsync(grad_verts, 0, (size_t)B * n_verts * 3 * sizeof(float), st) != hipSuccess)
+        if (!precleared() && hipMemsetAsync(grad_verts, 0, (size_t)B * n_verts * 3 * sizeof(float), st) != hipSuccess)
             return fail(G2S_ERR_LAUNCH, "hipMemsetAsync(grad_verts) failed");
         raster_bwd_samples<float><<<dim3(cdiv(bw_tiles, 4), B), 256, 0, st>>>(p);
     }

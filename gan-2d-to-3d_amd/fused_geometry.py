@@ -8,6 +8,17 @@ import torch
 from torch.autograd import Function
 
 from . import lib as _lib
+from . import zeropool as _zp
+
+
+def _cleared(shape, device):
+    """(tensor, from_pool): an accumulator the library call would otherwise clear with a memset of its own — a
+    slice of the step's cleared pool when one is active (then the call runs under lib.precleared), else plain
+    memory that the call clears itself."""
+    t = _zp.take(tuple(shape), device)
+    if t is not None:
+        return t, True
+    return torch.empty(shape, dtype=torch.float32, device=device), False
 
 
 def _f32c(t):
@@ -65,11 +76,12 @@ class WarpVertsFunction(Function):
         B, H, W = depth.shape
         need_rt = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         gdepth = torch.empty_like(depth)
-        grt = torch.empty((B, 12), dtype=torch.float32, device=depth.device) if need_rt else None
+        grt, pre = _cleared((B, 12), depth.device) if need_rt else (None, False)
         L = _lib.load()
-        _lib.check(L.g2s_warp_verts_bwd(_lib.ptr(depth), _lib.ptr(rays), _lib.ptr(R),
-                                        _lib.ptr(_f32c(gverts)), ctx.rcd, _lib.ptr(gdepth),
-                                        _lib.ptr(grt), B, H * W, _lib.stream()))
+        with _lib.precleared(pre):
+            _lib.check(L.g2s_warp_verts_bwd(_lib.ptr(depth), _lib.ptr(rays), _lib.ptr(R),
+                                            _lib.ptr(_f32c(gverts)), ctx.rcd, _lib.ptr(gdepth),
+                                            _lib.ptr(grt), B, H * W, _lib.stream()))
         gR = grt[:, :9].reshape(B, 3, 3) if need_rt else None
         gt = grt[:, 9:].reshape(B, 1, 3) if need_rt else None
         return gdepth, None, gR, gt, None
@@ -99,12 +111,13 @@ class InvWarpGridFunction(Function):
         B, H, W = depth.shape
         need_rt = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         gdepth = torch.empty_like(depth)
-        grt = torch.empty((B, 12), dtype=torch.float32, device=depth.device) if need_rt else None
+        grt, pre = _cleared((B, 12), depth.device) if need_rt else (None, False)
         Kc = (_lib.C.c_float * 9)(*K9)
         L = _lib.load()
-        _lib.check(L.g2s_inv_warp_grid_bwd(_lib.ptr(depth), _lib.ptr(rays), _lib.ptr(R), _lib.ptr(t),
-                                           Kc, rcd, _lib.ptr(_f32c(ggrid)), _lib.ptr(gdepth),
-                                           _lib.ptr(grt), B, H, W, _lib.stream()))
+        with _lib.precleared(pre):
+            _lib.check(L.g2s_inv_warp_grid_bwd(_lib.ptr(depth), _lib.ptr(rays), _lib.ptr(R), _lib.ptr(t),
+                                               Kc, rcd, _lib.ptr(_f32c(ggrid)), _lib.ptr(gdepth),
+                                               _lib.ptr(grt), B, H, W, _lib.stream()))
         gR = grt[:, :9].reshape(B, 3, 3) if need_rt else None
         gt = grt[:, 9:].reshape(B, 1, 3) if need_rt else None
         return gdepth, None, gR, gt, None, None
@@ -117,9 +130,10 @@ class SmoothLossFunction(Function):
     def forward(ctx, pred):
         p = _f32c(pred).reshape(-1, pred.shape[-2], pred.shape[-1])
         N, H, W = p.shape
-        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        loss, pre = _cleared((), p.device)
         L = _lib.load()
-        _lib.check(L.g2s_smooth_loss_fwd(_lib.ptr(p), _lib.ptr(loss), N, H, W, _lib.stream()))
+        with _lib.precleared(pre):
+            _lib.check(L.g2s_smooth_loss_fwd(_lib.ptr(p), _lib.ptr(loss), N, H, W, _lib.stream()))
         ctx.save_for_backward(p)
         ctx.shape = pred.shape
         return loss
@@ -190,12 +204,13 @@ class ShadingFunction(Function):
             gtexture = torch.zeros((B, 3, H, W), dtype=torch.float32, device=dev)
         gnormal = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
         galbedo = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
-        glight = torch.empty((B, 4), dtype=torch.float32, device=dev)
+        glight, pre = _cleared((B, 4), dev)
         gd = None if gdiffuse is None else _f32c(gdiffuse)
         L = _lib.load()
-        _lib.check(L.g2s_shading_bwd(_lib.ptr(normal), _lib.ptr(light), _lib.ptr(albedo), _lib.ptr(gd),
-                                     _lib.ptr(_f32c(gtexture)), _lib.ptr(gnormal), _lib.ptr(galbedo),
-                                     _lib.ptr(glight), B, Bn, Ba, H * W, _lib.stream()))
+        with _lib.precleared(pre):
+            _lib.check(L.g2s_shading_bwd(_lib.ptr(normal), _lib.ptr(light), _lib.ptr(albedo), _lib.ptr(gd),
+                                         _lib.ptr(_f32c(gtexture)), _lib.ptr(gnormal), _lib.ptr(galbedo),
+                                         _lib.ptr(glight), B, Bn, Ba, H * W, _lib.stream()))
         if Bn == 1 and B > 1:
             gnormal = gnormal.sum(0, keepdim=True)
         if Ba == 1 and B > 1:
@@ -226,9 +241,10 @@ class DepthHeadFunction(Function):
     def backward(ctx, g):
         raw, mean = ctx.saved_tensors
         g_raw = torch.empty_like(raw)
-        gsum = torch.empty(1, dtype=torch.float32, device=raw.device)
-        _lib.check(_lib.load().g2s_depth_head_bwd(_lib.ptr(raw), _lib.ptr(mean), _lib.ptr(_f32c(g)), _lib.ptr(g_raw),
-                                                  _lib.ptr(gsum), *ctx.args, _lib.stream()))
+        gsum, pre = _cleared((1,), raw.device)
+        with _lib.precleared(pre):
+            _lib.check(_lib.load().g2s_depth_head_bwd(_lib.ptr(raw), _lib.ptr(mean), _lib.ptr(_f32c(g)), _lib.ptr(g_raw),
+                                                      _lib.ptr(gsum), *ctx.args, _lib.stream()))
         return g_raw, None, None, None, None, None
 
 

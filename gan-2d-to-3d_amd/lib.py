@@ -29,6 +29,7 @@ SIGNATURES = {
     "g2s_grid_sample_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p]),
     "g2s_set_deterministic": (_i, [_i]),
     "g2s_get_deterministic": (_i, []),
+    "g2s_set_precleared": (_i, [_i]),
     "g2s_raster_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "g2s_raster_tune": (_i, [_i]),
     "g2s_raster_depth_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p, _f, _i, _i, _f, _f, _p, _p, _p, _p, _sz, _p]),
@@ -131,6 +132,23 @@ def set_deterministic(on=True):
     prev = bool(L.g2s_get_deterministic())
     check(L.g2s_set_deterministic(int(bool(on))))
     return prev
+
+
+class precleared:
+    """with precleared(on): <one library call> — g2s_set_precleared around the call: the accumulators that call
+    would clear itself come from the step's cleared pool (zeropool.take) and its memsets are skipped."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        if self.on:
+            self.prev = load().g2s_set_precleared(1)
+
+    def __exit__(self, *exc):
+        if self.on:
+            load().g2s_set_precleared(self.prev)
+        return False
 
 
 def check(rc):

@@ -7,6 +7,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import lib as _lib
+from .. import zeropool as _zp
 
 
 class _GridSample(Function):
@@ -27,15 +28,27 @@ class _GridSample(Function):
         x, grid = ctx.saved_tensors
         L = _lib.load()
         need_x, need_grid = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        gx = torch.empty_like(x) if need_x else None
         gg = torch.empty_like(grid) if need_grid else None
-        if gx is None and gg is None:
+        if not need_x and gg is None:
             return None, None, None, None
-        ws = None
+        # the scatter target (default mode: gx itself; deterministic mode: the fixed-point workspace) must start
+        # at zero: a slice of the step's cleared pool when there is one, else the call clears it with a memset
+        gx, ws, ws_bytes, pre = None, None, 0, False
         if need_x and L.g2s_get_deterministic():
-            ws = torch.empty(L.g2s_grid_sample_bwd_workspace_bytes(*ctx.args[:4]), dtype=torch.uint8, device=x.device)
-        _lib.check(L.g2s_grid_sample_bwd(_lib.ptr(gy.contiguous()), _lib.ptr(x), _lib.ptr(grid), _lib.ptr(gx), _lib.ptr(gg),
-                                         *ctx.args, _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream()))
+            ws_bytes = L.g2s_grid_sample_bwd_workspace_bytes(*ctx.args[:4])
+            ws = _zp.take(((ws_bytes + 3) // 4,), x.device)
+            pre = ws is not None
+            if ws is None:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            gx = torch.empty_like(x)
+        elif need_x:
+            gx = _zp.take(tuple(x.shape), x.device)
+            pre = gx is not None
+            if gx is None:
+                gx = torch.empty_like(x)
+        with _lib.precleared(pre):
+            _lib.check(L.g2s_grid_sample_bwd(_lib.ptr(gy.contiguous()), _lib.ptr(x), _lib.ptr(grid), _lib.ptr(gx), _lib.ptr(gg),
+                                             *ctx.args, _lib.ptr(ws), ws_bytes, _lib.stream()))
         return gx, gg, None, None
 
 

@@ -20,6 +20,7 @@ import torch
 from torch.autograd import Function
 
 from gan2shape_amd import lib as _lib
+from gan2shape_amd import zeropool as _zp
 
 DEFAULT_NEAR = 0.1
 DEFAULT_FAR = 100.0
@@ -88,16 +89,28 @@ class RenderDepthFunction(Function):
         K, orig_size, S, ssaa, F = ctx.meta
         B, N, _ = verts.shape
         g = grad_depth.contiguous().float()
-        gv = torch.empty_like(verts)
         L = _lib.load()
         Kc = (_lib.C.c_float * 9)(*K)
-        ws = None       # deterministic mode sums in fixed point in a scratch buffer (include/g2s.h)
+        # the scatter target must start at zero — default mode: the gradient itself; deterministic mode: the
+        # fixed-point scratch buffer (include/g2s.h).  A slice of the step's cleared pool when there is one
+        # (the call then runs under lib.precleared), else the call clears it with a memset of its own.
+        ws, ws_bytes, pre = None, 0, False
         if L.g2s_get_deterministic():
-            ws = torch.empty(L.g2s_raster_bwd_workspace_bytes(B, N), dtype=torch.uint8, device=verts.device)
-        _lib.check(L.g2s_raster_depth_bwd_ex(_lib.ptr(verts), _lib.ptr(faces), _lib.ptr(g),
-                                             _lib.ptr(fidx), _lib.ptr(bary), B, N, F, S, Kc, orig_size,
-                                             ssaa, _lib.ptr(gv), _lib.ptr(ws), ws.numel() if ws is not None else 0,
-                                             _lib.stream()))
+            ws_bytes = L.g2s_raster_bwd_workspace_bytes(B, N)
+            ws = _zp.take(((ws_bytes + 3) // 4,), verts.device)
+            pre = ws is not None
+            if ws is None:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=verts.device)
+            gv = torch.empty_like(verts)
+        else:
+            gv = _zp.take(tuple(verts.shape), verts.device)
+            pre = gv is not None
+            if gv is None:
+                gv = torch.empty_like(verts)
+        with _lib.precleared(pre):
+            _lib.check(L.g2s_raster_depth_bwd_ex(_lib.ptr(verts), _lib.ptr(faces), _lib.ptr(g),
+                                                 _lib.ptr(fidx), _lib.ptr(bary), B, N, F, S, Kc, orig_size,
+                                                 ssaa, _lib.ptr(gv), _lib.ptr(ws), ws_bytes, _lib.stream()))
         return gv, None, None, None, None, None, None, None, None
 
 

@@ -10,9 +10,10 @@
  *     never synchronises, never throws);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *   - returns G2S_OK (0) or a negative error code; g2s_last_error() gives a thread-local message;
- *   - re-entrant.  Thread-local state: the error string and the two tuning overrides
+ *   - re-entrant.  Thread-local state: the error string, the two tuning overrides
  *     g2s_modconv_tune / g2s_raster_tune (off by default; they select among launch configurations
- *     that produce the same results, and only affect the calling thread).  Process-global state:
+ *     that produce the same results, and only affect the calling thread) and g2s_set_precleared
+ *     (off by default: the caller has cleared the accumulators of the next call).  Process-global state:
  *     ONE flag, g2s_set_deterministic (off by default).  No environment variable is read.
  */
 #ifndef G2S_H
@@ -52,6 +53,15 @@ const char *g2s_last_error(void);
  * atomics over tiles).  Takes effect for launches issued after the call, from any thread. */
 int g2s_set_deterministic(int on);
 int g2s_get_deterministic(void);
+
+/* Caller-cleared accumulators (no reference counterpart; per THREAD, returns the previous value).  The backward
+ * functions below that accumulate into small outputs or workspaces clear them first with a memset of their own —
+ * one more launch each (14 of step 3's).  While this flag is on, the calling thread guarantees that those buffers
+ * are already zero (the Python side carves them from the step's one cleared pool, zeropool.py) and the memsets are
+ * skipped: g2s_warp_verts_bwd / g2s_inv_warp_grid_bwd (gRt), g2s_smooth_loss_fwd (loss), g2s_shading_bwd (glight),
+ * g2s_depth_head_bwd (gsum), g2s_grid_sample_bwd (gx, or the deterministic mode's fixed-point workspace),
+ * g2s_raster_depth_bwd(_ex) (grad_verts, or its fixed-point workspace).  Set it around ONE call and restore it. */
+int g2s_set_precleared(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Differentiable depth rasterizer.
