@@ -130,7 +130,9 @@ __global__ __launch_bounds__(W4THREADS) void wino4_kernel(Wino4Desc d) {
     // Every global -> LDS transfer is an LDS-DMA request in inline assembly: the compiler does not see
     // them, so it adds no waits of its own (with __builtin_amdgcn_global_load_lds every later DS instruction
     // that may alias waits for ALL outstanding requests, vmcnt(0), which makes the copy synchronous); their
-    // completion is stated once per K tile by the s_waitcnt vmcnt(0) before the hand-over barrier.
+    // completion is stated once per K tile by the s_waitcnt vmcnt(0) before the hand-over barrier.  (M0 is
+    // written inside the asm block without a clobber — clang rejects reserved registers in clobber lists with a
+    // warning; nothing else in this kernel uses M0: gfx9 DS instructions do not read it.)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(&L[0]);
     auto dma16 = [&](unsigned lds_float, const char *gp) {
         const unsigned la = lds0 + lds_float * 4;
