@@ -27,8 +27,9 @@
 //     A thread then transforms one 3x3 quadrant of V = B^T d B for one (tile, channel): five 16-byte LDS
 //     reads (a 5x5 corner of the patch; the outer column from the neighbour lane by a whole-wave DPP
 //     shift), 48 VALU operations, 9 values to the V stage.  (Loading the corners from global memory
-//     instead — 3.3x the bytes — ran at the same speed: the K tile is paced by how long its 48 KB of
-//     requests take to land within ONE iteration)
+//     instead — 3.3x the bytes — ran at the same speed; so did a deeper U ring, requests placed behind
+//     MFMAs, and no wait for them at all: what the requests cost is shared capacity beside the DS traffic,
+//     not latency — DESIGN §4.3b.)
 //   * Every transfer is an LDS-DMA request issued from inline assembly; the one s_waitcnt vmcnt(0) before the
 //     hand-over barrier states their completion (the compiler would add vmcnt(0) before every DS instruction
 //     after a __builtin_amdgcn_global_load_lds it cannot prove disjoint).
