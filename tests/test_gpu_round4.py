@@ -345,3 +345,52 @@ def test_channel_sum_is_the_bias_gradient(g2s):
         lib.check(L.g2s_channel_sum(lib.ptr(gy), lib.ptr(out), shape[0], shape[1], shape[2] * shape[3], lib.stream()))
         ref = gy.double().sum((0, 2, 3))
         assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), shape
+
+
+def test_precleared_skips_the_memset_and_the_pool_path_equals_the_plain_one(g2s):
+    """g2s_set_precleared (include/g2s.h): while the flag is on, g2s_shading_bwd adds into the caller's glight instead
+    of clearing it first (so a buffer prefilled with 1 comes back 1 too high — the memset is really skipped — and a
+    cleared one gives the plain result); the flag is per call (restored by lib.precleared); and the op-level wrappers
+    give bit-identical gradients with a step's zero pool active (accumulators carved from it) and without one."""
+    from gan2shape_amd import fused_geometry as fg, lib, zeropool
+    L = lib.load()
+    torch.manual_seed(3)
+    B, H, W = 4, 16, 16
+    normal = torch.nn.functional.normalize(torch.randn(B, H, W, 3, device="cuda"), dim=-1).contiguous()
+    light = torch.randn(B, 4, device="cuda")
+    albedo = torch.randn(B, 3, H, W, device="cuda")
+    gd, gt = torch.randn(B, 1, H, W, device="cuda"), torch.randn(B, 3, H, W, device="cuda")
+    gn, ga = torch.empty(B, H, W, 3, device="cuda"), torch.empty(B, 3, H, W, device="cuda")
+
+    def call(glight, flag):
+        with lib.precleared(flag):
+            lib.check(L.g2s_shading_bwd(lib.ptr(normal), lib.ptr(light), lib.ptr(albedo), lib.ptr(gd), lib.ptr(gt),
+                                        lib.ptr(gn), lib.ptr(ga), lib.ptr(glight), B, B, B, H * W, lib.stream()))
+        return glight.clone()
+
+    prev = lib.set_deterministic(True)      # one workgroup per image: the sums have a fixed order
+    try:
+        plain = call(torch.full((B, 4), 7.0, device="cuda"), False)              # cleared by the library
+        assert torch.equal(call(torch.zeros(B, 4, device="cuda"), True), plain)  # cleared by the caller
+        dirty = call(torch.ones(B, 4, device="cuda"), True)                      # NOT cleared by anyone
+        assert float((dirty - plain - 1.0).abs().max()) <= 1e-5 * max(1.0, float(plain.abs().max()))
+        assert L.g2s_set_precleared(0) == 0                                      # restored after every call
+        # wrapper level: gradients with and without an active pool
+        def grads():
+            n, l, a = normal.clone().requires_grad_(True), light.clone().requires_grad_(True), albedo.clone().requires_grad_(True)
+            diffuse, texture = fg.ShadingFunction.apply(n, l, a)
+            (diffuse * gd).sum().add((texture * gt).sum()).backward()
+            return n.grad, l.grad, a.grad
+        zeropool.end()
+        ref = grads()
+        for _ in range(2):          # first pass sizes the pool, second is served from it
+            zeropool.begin(97, torch.device("cuda", torch.cuda.current_device()))
+            got = grads()
+            served = zeropool._state["off"] > 0
+            zeropool.end()
+        assert served, "the second step did not carve its accumulators from the pool"
+        for r, g_ in zip(ref, got):
+            assert torch.equal(r, g_)
+    finally:
+        zeropool.end()
+        lib.set_deterministic(prev)
